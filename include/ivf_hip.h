@@ -1,0 +1,267 @@
+/* libivf_hip.so -- C-ABI of the MI355X (gfx950) video-saliency hot path.
+ *
+ * The reference (interpreting-video-features) has no FFI/plugin boundary: its hot
+ * path is plain PyTorch called from Python.  This header is therefore the
+ * build-defined boundary beneath the reference's Python call surface (SURVEY.md
+ * section 8b); each entry point names the reference code it replaces.  File:line
+ * citations are relative to /root/reference/video_features_pytorch/ ("smth" =
+ * FindMasksComparison_I3D_smth.py).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless its name ends in _host or
+ *    its type says otherwise; the caller owns all memory, the library never
+ *    allocates or frees device memory; scratch is passed in, sized by the
+ *    matching *_workspace_bytes() query;
+ *  - `stream` is a hipStream_t (0 = the null stream); every call only enqueues
+ *    work and never synchronises, so a call sequence can be captured in a hipGraph;
+ *  - return value 0 = ok, negative = error (IVF_ERR_*), message via
+ *    ivf_last_error() (thread-local);
+ *  - activations inside the library are channels-last [B, T, H, W, ld] fp32 with a
+ *    channel window (coff, C) inside the row of ld floats; reference tensors are
+ *    NCTHW [B, C, T, H, W] and are converted at the edges (freeze/reverse kernels
+ *    write channels-last directly).
+ */
+#ifndef IVF_HIP_H
+#define IVF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVF_OK 0
+#define IVF_ERR_BAD_ARG (-1)
+#define IVF_ERR_HIP (-2)
+#define IVF_ERR_UNSUPPORTED (-3)
+
+typedef void* ivf_stream_t; /* hipStream_t */
+
+const char* ivf_last_error(void);
+int ivf_version(void);
+
+/* ------------------------------------------------------------------ mask.py */
+
+/* mask.perturb_sequence(..., 'freeze') forward, mask.py:11-22.
+ * x [B,C,T,HW] NCTHW; mask [T] (mask_per_clip=0) or [B,T] (=1), already in [0,1];
+ * p: out_cpad==0 -> NCTHW, else channels-last [B,T,HW,out_cpad] (pad channels zero). */
+int ivf_freeze_fwd(const float* x, const float* mask, float* p, int B, int C, int T, int HW,
+                   int mask_per_clip, int out_cpad, ivf_stream_t stream);
+
+/* Backward of the same (autograd of mask.py:11-22 under smth:213).
+ * g: upstream gradient, NCTHW (g_cpad==0) or channels-last with row g_cpad.
+ * dmask [B,T] per-clip gradient (sum over B yourself for a shared mask; entry 0 is 0);
+ * dx NCTHW or NULL.  Deterministic two-stage reduction (no float atomics). */
+size_t ivf_freeze_bwd_workspace_bytes(int B, int T);
+int ivf_freeze_bwd(const float* x, const float* mask, const float* g, float* dmask, float* dx, int B,
+                   int C, int T, int HW, int mask_per_clip, int g_cpad, void* workspace,
+                   ivf_stream_t stream);
+
+/* find_submasks_from_mask, mask.py:60-85, plus the pairing rule of the 'reverse'
+ * perturbation, mask.py:40-56.  run[t] = index of the run containing frame t or -1;
+ * partner[t] = frame swapped with t (t itself if copied); weight[t] = mask value of
+ * the pair's first-half member (used for BOTH members, mask.py:50-56). */
+int ivf_submask_pairs(const float* mask, int T, float thresh, int* run, int* partner, float* weight,
+                      ivf_stream_t stream);
+
+/* mask.perturb_sequence(..., 'reverse') given the pairing above. */
+int ivf_reverse_fwd(const float* x, const int* partner, const float* weight, float* p, int B, int C,
+                    int T, int HW, int out_cpad, ivf_stream_t stream);
+
+/* mask.calc_tv_norm(mask, p, q), mask.py:88-100: val[b] and (optional) grad[b,:]. */
+int ivf_tv_norm(const float* mask, int B, int T, float p, float q, float* val, float* grad,
+                ivf_stream_t stream);
+
+/* Regulariser of the search loop, smth:198-200: sig = sigmoid(raw);
+ * terms[b] = {lam1*sum|sig|, lam2*TV33(sig)}; dreg_dsig = d(l1+tv)/dsig. */
+int ivf_mask_reg(const float* raw_mask, int B, int T, float lam1, float lam2, float* sig, float* terms,
+                 float* dreg_dsig, ivf_stream_t stream);
+
+/* torch.optim.Adam step on one tensor (smth:191,214); step counts from 1. */
+int ivf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n, int step,
+                  float lr, float beta1, float beta2, float eps, ivf_stream_t stream);
+
+/* Loop tail, smth:207-214: chain through the sigmoid, Adam step on raw_mask [B,T],
+ * traj_row[b] = (loss, l1, tv, score). */
+int ivf_search_step(float* raw_mask, const float* sig, const float* dscore_dsig, const float* dreg_dsig,
+                    const float* terms, const float* score, float* exp_avg, float* exp_avg_sq,
+                    float* traj_row, int B, int T, int step, float lr, float beta1, float beta2,
+                    float eps, ivf_stream_t stream);
+
+int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream);
+
+/* ------------------------------------------------------------------ Unit3D */
+
+/* One convolution as implicit GEMM on the fp32 matrix cores.  Forward of Unit3D
+ * (models/I3D_doubled.py:83-118: asymmetric zero pad + Conv3d + BN(eval) + ReLU) and,
+ * with the packed backward weights, its backward-data.  Channels-last in/out. */
+typedef struct {
+  int B, Ti, Hi, Wi;           /* input positions */
+  int Cin, in_ld, in_coff;     /* channel window read (Cin % 4 == 0) */
+  int To, Ho, Wo;              /* output positions (block grid when d2s) */
+  int Cout, out_ld, out_coff;  /* rows of the packed weight / channel window written */
+  int kT, kH, kW, sT, sH, sW;  /* kernel, stride */
+  int pT, pH, pW;              /* FRONT zero padding; back padding is implied by To/Ho/Wo */
+  int relu;                    /* max(.,0) in the epilogue */
+  int accumulate;              /* out += result (before relu / mask) */
+  int mask_ld, mask_coff;      /* geometry of relu_mask (same positions as out) */
+  int d2s;                     /* depth-to-space output: stride-2 backward-data */
+  int dT, dH, dW, dC;          /* d2s: real output dims and channels written */
+  int bsT, bsH, bsW;           /* d2s: block strides (forward strides, 1 or 2) */
+} ivf_conv3d_desc;
+
+/* out = epilogue(conv(in, w_packed)): v = acc*scale[n] + shift[n] (NULL = 1 / 0);
+ * relu_mask != NULL zeroes v where mask <= 0 (the ReLU below, for backward-data). */
+int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float* w_packed, const float* scale,
+               const float* shift, const float* relu_mask, float* out, ivf_stream_t stream);
+
+/* BatchNorm3d(eval) fold, I3D_doubled.py:75 (eps 1e-3). */
+int ivf_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                float* scale, float* shift, int C, ivf_stream_t stream);
+
+/* Reference weight [Cout][Cin][kT][kH][kW] -> forward pack [Cout][taps*CinPad]. */
+int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad, int kT,
+                        int kH, int kW, ivf_stream_t stream);
+
+/* Geometry of the backward-data convolution produced by ivf_conv3d_pack_bwd. */
+typedef struct {
+  int d2s;          /* 0: plain flipped conv (all strides 1); 1: depth-to-space form */
+  int kT, kH, kW;   /* kernel of the backward conv over dY */
+  int pT, pH, pW;   /* its front padding */
+  int rows;         /* rows of the packed weight (= Cout of the backward conv) */
+} ivf_conv3d_bwd_geom;
+
+/* Backward-data pack, BN scale folded in: [rows][taps_b*Cout]; needs
+ * rows*taps_b*Cout floats where taps_b = geom.kT*kH*kW (call with w_packed sized
+ * by ivf_conv3d_pack_bwd_elems). */
+size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int sT, int sH, int sW,
+                                 int pT, int pH, int pW);
+int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed, int Cout, int Cin,
+                        int CinPad, int kT, int kH, int kW, int sT, int sH, int sW, int pT, int pH,
+                        int pW, ivf_conv3d_bwd_geom* geom, ivf_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling / head */
+
+typedef struct {
+  int B, Ti, Hi, Wi, C, in_ld, in_coff;
+  int To, Ho, Wo, out_ld, out_coff;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW; /* front ZERO padding (I3D_doubled.py:36-39) */
+} ivf_pool3d_desc;
+
+/* MaxPool3dSamePadding.forward, I3D_doubled.py:15-40; argmax [positions_out][C] uint8
+ * (flat tap of the winner, first strict maximum, pad cells count as 0). */
+int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float* y, unsigned char* argmax,
+                      ivf_stream_t stream);
+int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, const unsigned char* argmax, float* dx,
+                      const float* relu_mask, int accumulate, ivf_stream_t stream);
+
+/* I3D head, I3D_doubled.py:360-380, for a pooling window covering the whole feature
+ * map: feat [B,npos,C] -> pooled [B,C] (optional) -> logits [B,K] -> probs [B,K]
+ * (softmax over K if softmax != 0, else a copy).  w is the reference
+ * logits.conv3d.weight viewed as [K][C]. */
+int ivf_head_fwd(const float* feat, const float* w, const float* bias, float* pooled, float* logits,
+                 float* probs, int B, int npos, int C, int K, int softmax, ivf_stream_t stream);
+
+/* Backward of the head.  Upstream gradient: dout [B,K] if non-NULL, else one-hot at
+ * target[b].  score[b] = probs[b,target[b]] (optional, needs target).
+ * dpooled [B,C] optional; dfeat [B,npos,C] optional, gated by feat > 0 when gate_relu. */
+int ivf_head_bwd(const float* feat, const float* w, const float* probs, const int* target,
+                 const float* dout, float* score, float* dpooled, float* dfeat, int B, int npos, int C,
+                 int K, int softmax, int gate_relu, ivf_stream_t stream);
+
+/* ------------------------------------------------------------------ Grad-CAM */
+
+/* grad_cam_videos.py:98-110: weights[b,k] = mean_pos grad; cam[b,pos] = relu(sum_k w*feat). */
+int ivf_gradcam_reduce(const float* feat, const float* grad, float* weights, float* cam, int B, int npos,
+                       int C, ivf_stream_t stream);
+
+/* grad_cam_videos.py:113-138: per temporal slice bilinear resize (sh,sw)->(H,W)
+ * (OpenCV INTER_LINEAR rule), repeat `step` frames, min/max normalise per slice block
+ * (per_frame) or per clip.  cam [B,nslice,sh,sw] -> out [B,nslice*step,H,W];
+ * minmax_ws: B*nslice*2 floats. */
+int ivf_cam_resize_normalise(const float* cam, float* out, float* minmax_ws, int B, int nslice, int sh,
+                             int sw, int H, int W, int step, int per_frame, ivf_stream_t stream);
+
+/* ------------------------------------------------------------------ whole I3D */
+
+typedef struct {
+  int B;                 /* maximum clips per call */
+  int C, T, H, W;        /* clip geometry, reference NCTHW */
+  int num_classes;
+  int stem_stride_t;     /* temporal stride of Conv3d_1a_7x7 (2, or last_stride) */
+  int pool4a_stride_t;   /* MaxPool3d_4a_3x3 */
+  int pool5a_stride_t;   /* MaxPool3d_5a_2x2 */
+  int head_kt, head_kh, head_kw; /* AvgPool3d window: (2,7,7) / (finalTimeLength,4,5) */
+  int softmax;           /* Model(softMax=...) */
+} ivf_i3d_config;
+
+typedef struct ivf_i3d ivf_i3d_t;
+
+/* Host-side plan (shapes, buffer offsets, launch list).  No device work. */
+int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out);
+void ivf_i3d_destroy(ivf_i3d_t* net);
+size_t ivf_i3d_weights_bytes(const ivf_i3d_t* net);
+size_t ivf_i3d_workspace_bytes(const ivf_i3d_t* net);
+/* Give the plan its two caller-owned device arenas (256-byte aligned). */
+int ivf_i3d_bind(ivf_i3d_t* net, void* weights_arena, void* workspace);
+
+/* Convolution units in reference registration order (I3D_doubled.py:229-334);
+ * name is the state_dict prefix, e.g. "Mixed_3b.b1a" or "logits". */
+int ivf_i3d_num_convs(const ivf_i3d_t* net);
+int ivf_i3d_conv_info(const ivf_i3d_t* net, int i, char* name64, int* cout, int* cin, int* kT, int* kH,
+                      int* kW, int* has_bn);
+/* Pack one unit from reference-layout device tensors: w [Cout][Cin][kT][kH][kW];
+ * BN tensors (NULL for the logits unit, which takes bias instead). */
+int ivf_i3d_load_conv(ivf_i3d_t* net, int i, const float* w, const float* bn_gamma, const float* bn_beta,
+                      const float* bn_mean, const float* bn_var, const float* bias, float bn_eps,
+                      ivf_stream_t stream);
+
+/* Model.forward, I3D_doubled.py:351-380, on b <= B clips.  x NCTHW.
+ * logits/probs [b,K] outputs (either may be NULL); activations stay in the workspace. */
+int ivf_i3d_forward(ivf_i3d_t* net, const float* x, int b, float* logits, float* probs,
+                    ivf_stream_t stream);
+/* Forward of an already perturbed channels-last clip held in the plan's input buffer. */
+int ivf_i3d_forward_staged(ivf_i3d_t* net, int b, float* logits, float* probs, ivf_stream_t stream);
+/* Device pointer of the plan's input buffer [B,T,H*W,4] (channels-last, C padded to 4). */
+float* ivf_i3d_input_buffer(ivf_i3d_t* net);
+/* Backward-data of the last forward: upstream dout [b,K] or one-hot target[b];
+ * writes score[b] (optional), dx NCTHW (optional); the channels-last gradient of
+ * the input stays in the workspace (ivf_i3d_input_grad_buffer). */
+int ivf_i3d_backward(ivf_i3d_t* net, int b, const int* target, const float* dout, float* score,
+                     float* dx, ivf_stream_t stream);
+float* ivf_i3d_input_grad_buffer(ivf_i3d_t* net);
+
+/* Named endpoint activations of the last forward (tests, Grad-CAM):
+ * channels-last [b,T,H,W,ld]; returns IVF_ERR_BAD_ARG for an unknown name. */
+int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** ptr, int* T, int* H, int* W, int* C,
+                     int* ld);
+
+/* The hot loop, smth:193-214, for b clips with per-clip masks, entirely on the
+ * device: N iterations of sigmoid/L1/TV -> freeze -> forward -> score -> backward
+ * -> freeze backward -> Adam.  raw_mask, exp_avg, exp_avg_sq [b,T] in/out;
+ * target [b]; traj [N,b,4] = (loss,l1,tv,score) or NULL; first_step = Adam step
+ * number of the first iteration (1 for a fresh search). */
+int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* target, float* raw_mask,
+                   float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
+                   float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream);
+
+/* Scores of perturbed clips (init_mask, mask.py:121-154, and the reverse score,
+ * smth:234-235): mode 0 = freeze with mask [b,T] as given (no sigmoid), mode 1 =
+ * reverse with mask [b,T]; probs [b,K]. */
+int ivf_i3d_perturbed_forward(ivf_i3d_t* net, const float* x, int b, const float* mask, int mode,
+                              float* probs, ivf_stream_t stream);
+
+/* GradCamVideo.__call__ for archType "I3D" / target layer Mixed_5c,
+ * grad_cam_videos.py:64-142, for b clips.  target[b] (device) selects the class;
+ * cam [b,T'*(T/T'),out_h,out_w] (input_spatial_size, grad_cam_videos.py:54-57);
+ * probs [b,K] optional. */
+int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int* target, int per_frame, int out_h,
+                    int out_w, float* cam, float* probs, ivf_stream_t stream);
+/* argmax over K of probs [b,K] -> target [b] (np.argmax, grad_cam_videos.py:69-70). */
+int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVF_HIP_H */

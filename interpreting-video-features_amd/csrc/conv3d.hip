@@ -1,0 +1,480 @@
+// 3-D convolution forward / backward-data as implicit GEMM on the gfx950 fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so results track
+// the reference's fp32 CPU path to rounding).
+//
+// Replaces, on the saliency path, torch.nn.Conv3d + F.pad + BatchNorm3d(eval) +
+// ReLU of the reference's Unit3D (video_features_pytorch/models/I3D_doubled.py:83-118)
+// and the autograd backward-data of the same (loss.backward(),
+// FindMasksComparison_I3D_smth.py:213).
+//
+// Data layout: activations are channels-last [B, T, H, W, ld] fp32 so the GEMM K
+// dimension (taps x input channels) is contiguous per tap and every global load
+// is a 16-byte vector of 4 channels.  Weights are packed [Cout][K] with
+// K = ((kt*kH + kh)*kW + kw)*Cin + ci (ci fastest), BN(eval) folded into a
+// per-channel scale/shift applied in the epilogue.
+//
+// GEMM view: D[m][n] = sum_k A[m][k] * Wp[n][k], m = output position
+// (b,to,ho,wo), n = output channel.  Tile BM x BN x 32, 256 threads = 4 waves,
+// each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  A and W chunks are
+// staged global -> registers -> LDS ([rows][32+4] floats: the +4 pad makes the
+// ds_read_b128 fragment reads conflict-free), the next chunk's global loads are
+// in flight while the current chunk's MFMAs run.
+#include "ivf_common.h"
+
+namespace ivf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct ConvKArgs {
+  const float* in;
+  const float* w;
+  float* out;
+  const float* scale;  // [Cout] or null
+  const float* shift;  // [Cout] or null
+  const float* mask;   // ReLU mask source (post-ReLU activation), or null
+  int B, Ti, Hi, Wi, Cin, in_ld, in_coff;
+  int To, Ho, Wo, Cout, out_ld, out_coff;
+  int mask_ld, mask_coff;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+  int K, M;
+  int relu, accumulate, d2s;
+  // depth-to-space output (stride-2 backward-data as a stride-1 conv over 2x2x2
+  // output blocks): real output dims
+  int dT, dH, dW, dC;
+  int bsT, bsH, bsW;  // block strides (the forward conv's strides, 1 or 2)
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  // Blocks are dealt round-robin over 8 XCDs; give each XCD a contiguous range of
+  // tiles so blocks sharing an A panel share an L2 (bijective form).
+  int q = nwg >> 3, r = nwg & 7;
+  int xcd = id & 7, pos = id >> 3;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
+  constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
+  constexpr int TN = BN / WN / 32;
+  constexpr int AROWS = BM / 32;    // rows of A each thread stages per chunk
+  constexpr int BROWS = BN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) float lds_a[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float lds_b[BN * LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+  const int mt = tile / a.ntiles;
+  const int nt = tile - mt * a.ntiles;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  // staging role: float4 group g of the 32-wide chunk, rows r0 + 32 j
+  const int g = tid & 7;
+  const int r0 = tid >> 3;
+
+  // decode this thread's A rows once
+  int a_base[AROWS];   // element offset of (b, ti0, hi0, wi0) before tap offset; may be "virtual"
+  int a_t0[AROWS], a_h0[AROWS], a_w0[AROWS];
+#pragma unroll
+  for (int j = 0; j < AROWS; ++j) {
+    int m = m0 + r0 + 32 * j;
+    if (m < a.M) {
+      int wo = m % a.Wo;
+      int t1 = m / a.Wo;
+      int ho = t1 % a.Ho;
+      int t2 = t1 / a.Ho;
+      int to = t2 % a.To;
+      int b = t2 / a.To;
+      a_t0[j] = to * a.sT - a.pT;
+      a_h0[j] = ho * a.sH - a.pH;
+      a_w0[j] = wo * a.sW - a.pW;
+      a_base[j] = b * a.Ti;
+    } else {
+      a_t0[j] = -100000;  // every tap out of range -> zero rows
+      a_h0[j] = 0;
+      a_w0[j] = 0;
+      a_base[j] = 0;
+    }
+  }
+  const float* wrow[BROWS];
+#pragma unroll
+  for (int j = 0; j < BROWS; ++j) {
+    int n = n0 + r0 + 32 * j;
+    wrow[j] = (n < a.Cout) ? a.w + (size_t)n * a.K : nullptr;
+  }
+
+  float4 ra[AROWS], rb[BROWS];
+  const int khw = a.kH * a.kW;
+
+  auto load_chunk = [&](int k0) {
+    int kk = k0 + 4 * g;
+    bool kvalid = kk < a.K;
+    int tap = kvalid ? kk / a.Cin : 0;
+    int ci = kk - tap * a.Cin;
+    int kt = tap / khw;
+    int rem = tap - kt * khw;
+    int kh = rem / a.kW;
+    int kw = rem - kh * a.kW;
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      int ti = a_t0[j] + kt, hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+      bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
+                (unsigned)wi < (unsigned)a.Wi;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        size_t off = ((size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + ci;
+        v = *reinterpret_cast<const float4*>(a.in + off);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kvalid && wrow[j]) v = *reinterpret_cast<const float4*>(wrow[j] + kk);
+      rb[j] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (a.K + BK - 1) / BK;
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j)
+      *reinterpret_cast<float4*>(&lds_a[(r0 + 32 * j) * LDS_LD + 4 * g]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j)
+      *reinterpret_cast<float4*>(&lds_b[(r0 + 32 * j) * LDS_LD + 4 * g]) = rb[j];
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk((c + 1) * BK);
+
+#pragma unroll
+    for (int k8 = 0; k8 < BK / 8; ++k8) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const float4*>(
+            &lds_a[(wm * (BM / WM) + i * 32 + li) * LDS_LD + k8 * 8 + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const float4*>(
+            &lds_b[(wn * (BN / WN) + j * 32 + li) * LDS_LD + k8 * 8 + 4 * lh]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column n = li, rows (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn * (BN / WN) + j * 32 + li;
+    if (n >= a.Cout) continue;
+    float sc = a.scale ? a.scale[n] : 1.f;
+    float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= a.M) continue;
+        float v = acc[i][j][r] * sc + sh;
+        size_t off;
+        if (a.d2s) {
+          // m = (b, tb, hb, wb) block; n = ((pt*2+ph)*2+pw)*dCpad + c
+          int wb = m % a.Wo;
+          int t1 = m / a.Wo;
+          int hb = t1 % a.Ho;
+          int t2 = t1 / a.Ho;
+          int tb = t2 % a.To;
+          int b = t2 / a.To;
+          int cpad = a.Cout >> 3;
+          int par = n / cpad, c = n - par * cpad;
+          int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+          if (pt >= a.bsT || ph >= a.bsH || pw >= a.bsW) continue;
+          int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
+          if (t >= a.dT || h >= a.dH || w >= a.dW || c >= a.dC) continue;
+          off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff + c;
+        } else {
+          off = (size_t)m * a.out_ld + a.out_coff + n;
+        }
+        if (a.accumulate) v += a.out[off];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (a.mask) {
+          size_t moff = (size_t)m * a.mask_ld + a.mask_coff + n;
+          if (!(a.mask[moff] > 0.f)) v = 0.f;
+        }
+        a.out[off] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight packing
+// Reference layout [Cout][Cin][kT][kH][kW] (I3D_doubled.py:64-71) ->
+// forward pack  Wf[co][(tap)*CinP + ci], zero for ci >= Cin (CinP = padded Cin)
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                int Cin, int CinP, int taps) {
+  size_t total = (size_t)Cout * taps * CinP;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int ci = i % CinP;
+    size_t r = i / CinP;
+    int tap = r % taps;
+    int co = r / taps;
+    out[i] = ci < Cin ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+  }
+}
+
+// backward-data pack for a stride-1 conv: a conv over dY with flipped taps,
+// Wb[ci][(tapf)*Cout + co] = scale[co] * W[co][ci][kT-1-kt][kH-1-kh][kW-1-kw]
+__global__ void pack_bwd_s1_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                   float* __restrict__ out, int Cout, int Cin, int CinRows, int kT,
+                                   int kH, int kW) {
+  int taps = kT * kH * kW;
+  size_t total = (size_t)CinRows * taps * Cout;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int co = i % Cout;
+    size_t r = i / Cout;
+    int tapf = r % taps;
+    int ci = r / taps;
+    int tap = taps - 1 - tapf;  // flipping all three dims == reversing the flat tap index
+    float s = scale ? scale[co] : 1.f;
+    out[i] = ci < Cin ? s * w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+  }
+}
+
+// backward-data pack for stride 2 in every strided dim, as a stride-1 conv over dY
+// producing 2x2x2 output blocks (depth-to-space): for block offset d in [0,kb)
+// (kb = ceil(k/2)+... see host), parity p, the forward tap is k = p + pad - 2*(d - dlo)
+// rows n = ((pt*2+ph)*2+pw)*CinP + ci ; cols (dt*KH+dh)*KW+dw)*Cout + co
+struct D2SPack {
+  int kT, kH, kW;     // forward kernel
+  int sT, sH, sW;     // forward strides (1 or 2 each)
+  int pT, pH, pW;     // forward front pads
+  int KT, KH, KW;     // block-conv kernel extents
+  int oT, oH, oW;     // block-conv front pads (dY index = blk + d - o)
+};
+__global__ void pack_bwd_d2s_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                    float* __restrict__ out, int Cout, int Cin, int CinP, D2SPack p) {
+  int taps = p.kT * p.kH * p.kW;
+  int btaps = p.KT * p.KH * p.KW;
+  size_t total = (size_t)8 * CinP * btaps * Cout;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int co = i % Cout;
+    size_t r = i / Cout;
+    int bt = r % btaps;
+    int n = r / btaps;
+    int ci = n % CinP, par = n / CinP;
+    int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+    int dw = bt % p.KW, dh = (bt / p.KW) % p.KH, dt = bt / (p.KW * p.KH);
+    // input index x = s*blk + par (par < s), output index o = blk + d - off;
+    // forward: x = o*s - pad + k  =>  k = par + pad - s*(d - off)
+    int kt = pt + p.pT - p.sT * (dt - p.oT);
+    int kh = ph + p.pH - p.sH * (dh - p.oH);
+    int kw = pw + p.pW - p.sW * (dw - p.oW);
+    bool ok = ci < Cin && pt < p.sT && ph < p.sH && pw < p.sW && kt >= 0 && kt < p.kT && kh >= 0 &&
+              kh < p.kH && kw >= 0 && kw < p.kW;
+    float v = 0.f;
+    if (ok) {
+      int tap = (kt * p.kH + kh) * p.kW + kw;
+      v = (scale ? scale[co] : 1.f) * w[((size_t)co * Cin + ci) * taps + tap];
+    }
+    out[i] = v;
+  }
+}
+
+// BN(eval) fold: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+// (I3D_doubled.py:75 eps=1e-3; torch batch_norm eval formula).
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean,
+                               const float* var, float eps, float* scale, float* shift, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - mean[c] * s;
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_variant(ConvKArgs& a, hipStream_t s) {
+  a.mtiles = cdiv(a.M, BM);
+  a.ntiles = cdiv(a.Cout, BN);
+  dim3 grid(a.mtiles * a.ntiles);
+  hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+int conv_launch(ConvKArgs& a, hipStream_t s) {
+  // pick BN to minimise padded columns; ties go to the wider tile
+  int n128 = cdiv(a.Cout, 128) * 128, n64 = cdiv(a.Cout, 64) * 64, n32 = cdiv(a.Cout, 32) * 32;
+  if (n128 <= n64 && n128 <= n32) return launch_variant<128, 128, 2, 2>(a, s);
+  if (n64 <= n32) return launch_variant<128, 64, 4, 1>(a, s);
+  return launch_variant<128, 32, 4, 1>(a, s);
+}
+
+// Extent / front offset of the backward conv along one dim.  Input x = s*blk + par
+// receives from outputs o with forward tap k = x + pad - s*o in [0,k): o = blk + d,
+// d in [dlo, dhi], dlo = ceil((pad-(k-1))/s), dhi = floor((s-1+pad)/s).
+static void bwd_span(int k, int st, int pad, int* K, int* off) {
+  if (st == 1) { *K = k; *off = k - 1 - pad; return; }
+  int lo_num = pad - (k - 1);
+  int dlo = lo_num >= 0 ? (lo_num + st - 1) / st : -((-lo_num) / st);
+  int dhi = (st - 1 + pad) / st;
+  *K = dhi - dlo + 1;
+  *off = -dlo;
+}
+
+static int check_desc(const ivf_conv3d_desc* d) {
+  IVF_CHECK_ARG(d != nullptr, "conv3d: null descriptor");
+  IVF_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0, "conv3d: bad input dims");
+  IVF_CHECK_ARG(d->Cin > 0 && d->Cin % 4 == 0, "conv3d: Cin (%d) must be a positive multiple of 4", d->Cin);
+  IVF_CHECK_ARG(d->in_ld % 4 == 0 && d->in_coff % 4 == 0 && d->in_coff + d->Cin <= d->in_ld,
+                "conv3d: input channel window [%d,+%d) must be 4-aligned inside ld %d", d->in_coff,
+                d->Cin, d->in_ld);
+  IVF_CHECK_ARG(d->Cout > 0 && d->out_coff >= 0, "conv3d: bad Cout");
+  IVF_CHECK_ARG(d->kT > 0 && d->kH > 0 && d->kW > 0 && d->sT > 0 && d->sH > 0 && d->sW > 0,
+                "conv3d: bad kernel/stride");
+  IVF_CHECK_ARG(d->To > 0 && d->Ho > 0 && d->Wo > 0, "conv3d: bad output dims");
+  long long in_elems = (long long)d->B * d->Ti * d->Hi * d->Wi * d->in_ld;
+  IVF_CHECK_ARG(in_elems < (1ll << 40), "conv3d: input too large");
+  IVF_CHECK_ARG((long long)d->B * d->To * d->Ho * d->Wo < (1ll << 31) &&
+                    (long long)d->B * d->Ti * d->Hi * d->Wi < (1ll << 31),
+                "conv3d: position count exceeds int32");
+  return IVF_OK;
+}
+
+}  // namespace ivf
+
+using namespace ivf;
+
+extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float* w_packed,
+                          const float* scale, const float* shift, const float* relu_mask,
+                          float* out, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_desc(d));
+  IVF_CHECK_ARG(in && w_packed && out, "conv3d: null pointer");
+  ConvKArgs a;
+  a.in = in; a.w = w_packed; a.out = out; a.scale = scale; a.shift = shift; a.mask = relu_mask;
+  a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.in_ld = d->in_ld;
+  a.in_coff = d->in_coff;
+  a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_ld = d->out_ld;
+  a.out_coff = d->out_coff; a.mask_ld = d->mask_ld; a.mask_coff = d->mask_coff;
+  a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW;
+  a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
+  a.K = d->kT * d->kH * d->kW * d->Cin;
+  a.M = d->B * d->To * d->Ho * d->Wo;
+  a.relu = d->relu; a.accumulate = d->accumulate; a.d2s = d->d2s;
+  a.dT = d->dT; a.dH = d->dH; a.dW = d->dW; a.dC = d->dC;
+  a.bsT = d->bsT; a.bsH = d->bsH; a.bsW = d->bsW;
+  if (d->d2s) {
+    IVF_CHECK_ARG(relu_mask == nullptr, "conv3d: relu_mask unsupported with depth-to-space");
+    IVF_CHECK_ARG(d->bsT >= 1 && d->bsT <= 2 && d->bsH >= 1 && d->bsH <= 2 && d->bsW >= 1 && d->bsW <= 2,
+                  "conv3d: block strides must be 1 or 2");
+    IVF_CHECK_ARG(d->Cout % 8 == 0, "conv3d: depth-to-space needs Cout = 8 * Cpad");
+    IVF_CHECK_ARG(d->dT > 0 && d->dH > 0 && d->dW > 0 && d->dC > 0 && d->dC <= d->Cout / 8,
+                  "conv3d: bad depth-to-space dims");
+    IVF_CHECK_ARG(d->out_coff + d->dC <= d->out_ld, "conv3d: d2s output window outside ld");
+  } else {
+    IVF_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld, "conv3d: output window outside ld");
+  }
+  return conv_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int ivf_bn_fold(const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, float* scale, float* shift, int C,
+                           ivf_stream_t stream) {
+  IVF_CHECK_ARG(gamma && beta && mean && var && scale && shift && C > 0, "bn_fold: bad args");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma,
+                     beta, mean, var, eps, scale, shift, C);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin,
+                                   int CinPad, int kT, int kH, int kW, ivf_stream_t stream) {
+  IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0,
+                "pack_fwd: bad args");
+  int taps = kT * kH * kW;
+  size_t total = (size_t)Cout * taps * CinPad;
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
+                     dim3(256), 0, (hipStream_t)stream, w_ref, w_packed, Cout, Cin, CinPad, taps);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed,
+                                   int Cout, int Cin, int CinPad, int kT, int kH, int kW, int sT,
+                                   int sH, int sW, int pT, int pH, int pW,
+                                   ivf_conv3d_bwd_geom* geom, ivf_stream_t stream) {
+  IVF_CHECK_ARG(w_ref && w_packed && geom && Cout > 0 && Cout % 4 == 0 && Cin > 0 && CinPad >= Cin,
+                "pack_bwd: bad args (Cout must be a multiple of 4)");
+  IVF_CHECK_ARG(sT >= 1 && sT <= 2 && sH >= 1 && sH <= 2 && sW >= 1 && sW <= 2,
+                "pack_bwd: strides must be 1 or 2");
+  hipStream_t s = (hipStream_t)stream;
+  if (sT == 1 && sH == 1 && sW == 1) {
+    geom->d2s = 0;
+    geom->kT = kT; geom->kH = kH; geom->kW = kW;
+    geom->pT = kT - 1 - pT; geom->pH = kH - 1 - pH; geom->pW = kW - 1 - pW;
+    geom->rows = CinPad;
+    size_t total = (size_t)CinPad * kT * kH * kW * Cout;
+    hipLaunchKernelGGL(pack_bwd_s1_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
+                       dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, kT, kH, kW);
+    IVF_CHECK_LAUNCH();
+    return IVF_OK;
+  }
+  auto span = bwd_span;
+  D2SPack p;
+  p.kT = kT; p.kH = kH; p.kW = kW; p.sT = sT; p.sH = sH; p.sW = sW; p.pT = pT; p.pH = pH; p.pW = pW;
+  span(kT, sT, pT, &p.KT, &p.oT);
+  span(kH, sH, pH, &p.KH, &p.oH);
+  span(kW, sW, pW, &p.KW, &p.oW);
+  geom->d2s = 1;
+  geom->kT = p.KT; geom->kH = p.KH; geom->kW = p.KW;
+  geom->pT = p.oT; geom->pH = p.oH; geom->pW = p.oW;
+  geom->rows = 8 * CinPad;
+  size_t total = (size_t)8 * CinPad * p.KT * p.KH * p.KW * Cout;
+  hipLaunchKernelGGL(pack_bwd_d2s_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
+                     dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, p);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int sT, int sH,
+                                            int sW, int pT, int pH, int pW) {
+  if (sT == 1 && sH == 1 && sW == 1) return (size_t)CinPad * kT * kH * kW * Cout;
+  int KT, KH, KW, o;
+  bwd_span(kT, sT, pT, &KT, &o);
+  bwd_span(kH, sH, pH, &KH, &o);
+  bwd_span(kW, sW, pW, &KW, &o);
+  return (size_t)8 * CinPad * KT * KH * KW * Cout;
+}

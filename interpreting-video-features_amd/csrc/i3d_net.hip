@@ -1,0 +1,651 @@
+// Whole-network plan for the Inception-v1 I3D of the reference
+// (video_features_pytorch/models/I3D_doubled.py:149-380, KTH head of
+// I3D_doubled_kth.py:302-308): explicit forward and backward-DATA launch lists over
+// caller-owned arenas, the perturbation-mask search loop
+// (FindMasksComparison_I3D_smth.py:193-214) and Grad-CAM (grad_cam_videos.py:64-142)
+// driven entirely from the host side of this library with no device sync.
+//
+// No autograd: only dL/d(input) is propagated, activations are kept
+// once as the ReLU gates, Inception branches write straight into their slice of the
+// concatenated output (no torch.cat copy).
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ivf_common.h"
+
+namespace ivf {
+
+struct ActBuf {
+  int T, H, W, C;     // channels-last [B,T,H,W,C]
+  bool relu_out;      // produced by Unit3D ReLU (or a concat of such)
+  size_t act_off = 0, grad_off = 0;   // float offsets into the workspace
+  int consumers = 0;
+  std::string name;
+  size_t per_clip() const { return (size_t)T * H * W * C; }
+};
+
+struct ConvLayer {
+  std::string name;
+  int cin, cinp, cout;
+  int k[3], s[3];
+  bool has_bn;
+  size_t wf_off = 0, wb_off = 0, scale_off = 0, shift_off = 0;  // float offsets in weights arena
+  size_t wf_elems = 0, wb_elems = 0;
+  ivf_conv3d_bwd_geom geom{};
+  int pad[3] = {0, 0, 0};   // forward front pads for the planned input size
+};
+
+struct Op {
+  enum Type { CONV, POOL } type;
+  int src, dst;
+  int src_coff, cin;   // channel window read from src
+  int dst_coff, cout;
+  int conv = -1;
+  int k[3], s[3], p[3];
+  size_t idx_off = 0;  // pool arg-max bytes offset (in bytes, inside workspace)
+  // backward bookkeeping for grad(src)
+  bool bwd_accumulate = false, bwd_mask = false;
+};
+
+}  // namespace ivf
+
+using namespace ivf;
+
+struct ivf_i3d {
+  ivf_i3d_config cfg;
+  std::vector<ActBuf> bufs;
+  std::vector<ConvLayer> convs;   // registration order, last = logits
+  std::vector<Op> ops;
+  int feat_buf = -1;
+  size_t weights_floats = 0;
+  size_t ws_bytes = 0;
+  // misc workspace offsets (bytes)
+  size_t off_logits, off_probs, off_pooled, off_dpooled, off_score, off_sig, off_terms, off_dreg, off_dsig,
+      off_fbwd, off_target, off_cam, off_camw, off_mm, off_dfeat_raw, off_pair;
+  float* warena = nullptr;
+  char* ws = nullptr;
+  std::vector<bool> loaded;
+
+  float* act(int i) const { return (float*)ws + bufs[i].act_off; }
+  float* grad(int i) const { return (float*)ws + bufs[i].grad_off; }
+  template <class T>
+  T* at(size_t off) const { return (T*)(ws + off); }
+};
+
+namespace ivf {
+
+static const char* kInception[] = {"Mixed_3b", "Mixed_3c", "Mixed_4b", "Mixed_4c", "Mixed_4d",
+                                   "Mixed_4e", "Mixed_4f", "Mixed_5b", "Mixed_5c"};
+static const int kIncTable[9][7] = {
+    {192, 64, 96, 128, 16, 32, 32},    {256, 128, 128, 192, 32, 96, 64},
+    {480, 192, 96, 208, 16, 48, 64},   {512, 160, 112, 224, 24, 64, 64},
+    {512, 128, 128, 256, 24, 64, 64},  {512, 112, 144, 288, 32, 64, 64},
+    {528, 256, 160, 320, 32, 128, 128}, {832, 256, 160, 320, 32, 128, 128},
+    {832, 384, 192, 384, 48, 128, 128}};
+
+struct Builder {
+  ivf_i3d* n;
+  int add_buf(const std::string& name, int T, int H, int W, int C, bool relu) {
+    ActBuf b;
+    b.name = name; b.T = T; b.H = H; b.W = W; b.C = C; b.relu_out = relu;
+    n->bufs.push_back(b);
+    return (int)n->bufs.size() - 1;
+  }
+  int add_conv_layer(const std::string& name, int cin, int cout, int kt, int kh, int kw, int st, int sh,
+                     int sw, bool bn) {
+    ConvLayer c;
+    c.name = name; c.cin = cin; c.cinp = (cin + 3) / 4 * 4; c.cout = cout;
+    c.k[0] = kt; c.k[1] = kh; c.k[2] = kw; c.s[0] = st; c.s[1] = sh; c.s[2] = sw; c.has_bn = bn;
+    n->convs.push_back(c);
+    return (int)n->convs.size() - 1;
+  }
+  // conv op: src window -> dst window; dst buffer created by caller
+  void conv_op(int layer, int src, int src_coff, int dst, int dst_coff) {
+    ConvLayer& c = n->convs[layer];
+    const ActBuf& s = n->bufs[src];
+    Op o{};
+    o.type = Op::CONV; o.src = src; o.dst = dst; o.src_coff = src_coff; o.cin = c.cinp;
+    o.dst_coff = dst_coff; o.cout = c.cout; o.conv = layer;
+    int dims[3] = {s.T, s.H, s.W};
+    for (int d = 0; d < 3; ++d) {
+      o.k[d] = c.k[d]; o.s[d] = c.s[d];
+      int f, bk;
+      same_pad(dims[d], c.k[d], c.s[d], &f, &bk);
+      o.p[d] = f; c.pad[d] = f;
+    }
+    n->ops.push_back(o);
+    n->bufs[src].consumers++;
+  }
+  void pool_op(int src, int dst, int kt, int kh, int kw, int st, int sh, int sw) {
+    const ActBuf& s = n->bufs[src];
+    Op o{};
+    o.type = Op::POOL; o.src = src; o.dst = dst; o.src_coff = 0; o.cin = s.C; o.dst_coff = 0; o.cout = s.C;
+    int k[3] = {kt, kh, kw}, st3[3] = {st, sh, sw}, dims[3] = {s.T, s.H, s.W};
+    for (int d = 0; d < 3; ++d) {
+      o.k[d] = k[d]; o.s[d] = st3[d];
+      int f, bk;
+      same_pad(dims[d], k[d], st3[d], &f, &bk);
+      o.p[d] = f;
+    }
+    n->ops.push_back(o);
+    n->bufs[src].consumers++;
+  }
+};
+
+static int build_plan(ivf_i3d* n) {
+  const ivf_i3d_config& c = n->cfg;
+  Builder b{n};
+  // buffer 0: (perturbed) clip, channels-last padded to 4
+  int x = b.add_buf("input", c.T, c.H, c.W, 4, false);
+  auto unit = [&](const std::string& name, int src, int cin, int cout, int k, int st, int ss) {
+    const ActBuf& s = n->bufs[src];
+    int T = same_out(s.T, k, st), H = same_out(s.H, k, ss), W = same_out(s.W, k, ss);
+    int dst = b.add_buf(name, T, H, W, cout, true);
+    int L = b.add_conv_layer(name, cin, cout, k, k, k, st, ss, ss, true);
+    b.conv_op(L, src, 0, dst, 0);
+    return dst;
+  };
+  auto pool = [&](const std::string& name, int src, int kt, int ks, int st, int ss) {
+    const ActBuf& s = n->bufs[src];
+    int dst = b.add_buf(name, same_out(s.T, kt, st), same_out(s.H, ks, ss), same_out(s.W, ks, ss), s.C, false);
+    b.pool_op(src, dst, kt, ks, ks, st, ss, ss);
+    return dst;
+  };
+  x = unit("Conv3d_1a_7x7", x, c.C, 64, 7, c.stem_stride_t, 2);
+  x = pool("MaxPool3d_2a_3x3", x, 1, 3, 1, 2);
+  x = unit("Conv3d_2b_1x1", x, 64, 64, 1, 1, 1);
+  x = unit("Conv3d_2c_3x3", x, 64, 192, 3, 1, 1);
+  x = pool("MaxPool3d_3a_3x3", x, 1, 3, 1, 2);
+  for (int m = 0; m < 9; ++m) {
+    if (m == 2) x = pool("MaxPool3d_4a_3x3", x, 3, 3, c.pool4a_stride_t, 2);
+    if (m == 7) x = pool("MaxPool3d_5a_2x2", x, 2, 2, c.pool5a_stride_t, 2);
+    const int* t = kIncTable[m];
+    std::string nm = kInception[m];
+    const ActBuf s = n->bufs[x];
+    if (s.C != t[0]) { set_error("plan: channel mismatch at %s", nm.c_str()); return IVF_ERR_BAD_ARG; }
+    int ctot = t[1] + t[3] + t[5] + t[6];
+    int y = b.add_buf(nm, s.T, s.H, s.W, ctot, true);
+    int l0 = b.add_conv_layer(nm + ".b0", t[0], t[1], 1, 1, 1, 1, 1, 1, true);
+    int l1a = b.add_conv_layer(nm + ".b1a", t[0], t[2], 1, 1, 1, 1, 1, 1, true);
+    int l1b = b.add_conv_layer(nm + ".b1b", t[2], t[3], 3, 3, 3, 1, 1, 1, true);
+    int l2a = b.add_conv_layer(nm + ".b2a", t[0], t[4], 1, 1, 1, 1, 1, 1, true);
+    int l2b = b.add_conv_layer(nm + ".b2b", t[4], t[5], 3, 3, 3, 1, 1, 1, true);
+    int l3b = b.add_conv_layer(nm + ".b3b", t[0], t[6], 1, 1, 1, 1, 1, 1, true);
+    int t1 = b.add_buf(nm + ".b1a", s.T, s.H, s.W, t[2], true);
+    int t2 = b.add_buf(nm + ".b2a", s.T, s.H, s.W, t[4], true);
+    int t3 = b.add_buf(nm + ".b3a", s.T, s.H, s.W, t[0], false);
+    b.conv_op(l0, x, 0, y, 0);
+    b.conv_op(l1a, x, 0, t1, 0);
+    b.conv_op(l1b, t1, 0, y, t[1]);
+    b.conv_op(l2a, x, 0, t2, 0);
+    b.conv_op(l2b, t2, 0, y, t[1] + t[3]);
+    b.pool_op(x, t3, 3, 3, 3, 1, 1, 1);
+    b.conv_op(l3b, t3, 0, y, t[1] + t[3] + t[5]);
+    x = y;
+  }
+  n->feat_buf = x;
+  b.add_conv_layer("logits", 1024, c.num_classes, 1, 1, 1, 1, 1, 1, false);
+  const ActBuf& f = n->bufs[x];
+  if (f.T != c.head_kt || f.H != c.head_kh || f.W != c.head_kw) {
+    set_error("i3d: head AvgPool3d window (%d,%d,%d) must cover the Mixed_5c map (%d,%d,%d); "
+              "other windows give a [B,K,t] output the reference squeezes inconsistently (SURVEY F13)",
+              c.head_kt, c.head_kh, c.head_kw, f.T, f.H, f.W);
+    return IVF_ERR_UNSUPPORTED;
+  }
+
+  // backward flags: walk ops in reverse; the first writer of grad(src) overwrites,
+  // later ones accumulate, the last applies the ReLU gate of src.
+  std::vector<int> seen(n->bufs.size(), 0);
+  for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
+    Op& o = n->ops[i];
+    o.bwd_accumulate = seen[o.src] > 0;
+    seen[o.src]++;
+    o.bwd_mask = (seen[o.src] == n->bufs[o.src].consumers) && n->bufs[o.src].relu_out;
+  }
+
+  // ---- weights arena layout (floats)
+  size_t w = 0;
+  auto take = [&](size_t elems) { size_t o = w; w += (elems + 63) / 64 * 64; return o; };
+  for (size_t i = 0; i < n->convs.size(); ++i) {
+    ConvLayer& L = n->convs[i];
+    int taps = L.k[0] * L.k[1] * L.k[2];
+    if (L.name == "logits") {
+      L.wf_elems = (size_t)L.cout * L.cin;
+      L.wf_off = take(L.wf_elems);
+      L.shift_off = take(L.cout);
+      continue;
+    }
+    L.wf_elems = (size_t)L.cout * taps * L.cinp;
+    L.wf_off = take(L.wf_elems);
+    L.wb_elems = ivf_conv3d_pack_bwd_elems(L.cout, L.cinp, L.k[0], L.k[1], L.k[2], L.s[0], L.s[1], L.s[2],
+                                           L.pad[0], L.pad[1], L.pad[2]);
+    L.wb_off = take(L.wb_elems);
+    L.scale_off = take(L.cout);
+    L.shift_off = take(L.cout);
+  }
+  n->weights_floats = w;
+
+  // ---- workspace layout
+  const size_t B = c.B;
+  size_t fl = 0;  // floats
+  auto takef = [&](size_t elems) { size_t o = fl; fl += (elems + 63) / 64 * 64; return o; };
+  for (auto& bf : n->bufs) {
+    bf.act_off = takef(B * bf.per_clip());
+    bf.grad_off = takef(B * bf.per_clip());
+  }
+  size_t bytes = fl * sizeof(float);
+  auto takeb = [&](size_t nbytes) { size_t o = bytes; bytes += align_up(nbytes, 256); return o; };
+  for (auto& o : n->ops)
+    if (o.type == Op::POOL) {
+      const ActBuf& d = n->bufs[o.dst];
+      o.idx_off = takeb(B * d.per_clip());
+    }
+  const int K = c.num_classes, T = c.T;
+  n->off_logits = takeb(B * K * 4);
+  n->off_probs = takeb(B * K * 4);
+  n->off_pooled = takeb(B * 1024 * 4);
+  n->off_dpooled = takeb(B * 1024 * 4);
+  n->off_score = takeb(B * 4);
+  n->off_sig = takeb(B * T * 4);
+  n->off_terms = takeb(B * 2 * 4);
+  n->off_dreg = takeb(B * T * 4);
+  n->off_dsig = takeb(B * T * 4);
+  n->off_fbwd = takeb(ivf_freeze_bwd_workspace_bytes((int)B, T));
+  n->off_target = takeb(B * 4);
+  n->off_cam = takeb(B * f.T * f.H * f.W * 4);
+  n->off_camw = takeb(B * 1024 * 4);
+  n->off_mm = takeb(B * f.T * 2 * 4);
+  n->off_dfeat_raw = takeb(B * f.per_clip() * 4);
+  n->off_pair = takeb(B * T * 12);
+  n->ws_bytes = bytes;
+  n->loaded.assign(n->convs.size(), false);
+  return IVF_OK;
+}
+
+static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
+  const ActBuf& s = n->bufs[o.src];
+  const ActBuf& t = n->bufs[o.dst];
+  memset(d, 0, sizeof(*d));
+  d->B = b; d->Ti = s.T; d->Hi = s.H; d->Wi = s.W; d->Cin = o.cin; d->in_ld = s.C; d->in_coff = o.src_coff;
+  d->To = t.T; d->Ho = t.H; d->Wo = t.W; d->Cout = o.cout; d->out_ld = t.C; d->out_coff = o.dst_coff;
+  d->kT = o.k[0]; d->kH = o.k[1]; d->kW = o.k[2]; d->sT = o.s[0]; d->sH = o.s[1]; d->sW = o.s[2];
+  d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
+  d->relu = 1;
+}
+
+static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
+  const ActBuf& s = n->bufs[o.src];   // gradient written here
+  const ActBuf& t = n->bufs[o.dst];   // gradient read from here
+  const ConvLayer& L = n->convs[o.conv];
+  memset(d, 0, sizeof(*d));
+  d->B = b; d->Ti = t.T; d->Hi = t.H; d->Wi = t.W; d->Cin = o.cout; d->in_ld = t.C; d->in_coff = o.dst_coff;
+  d->kT = L.geom.kT; d->kH = L.geom.kH; d->kW = L.geom.kW; d->sT = d->sH = d->sW = 1;
+  d->pT = L.geom.pT; d->pH = L.geom.pH; d->pW = L.geom.pW;
+  d->out_ld = s.C; d->out_coff = o.src_coff;
+  d->accumulate = o.bwd_accumulate;
+  d->mask_ld = s.C; d->mask_coff = o.src_coff;
+  if (L.geom.d2s) {
+    d->d2s = 1;
+    d->bsT = o.s[0]; d->bsH = o.s[1]; d->bsW = o.s[2];
+    d->To = cdiv(s.T, o.s[0]); d->Ho = cdiv(s.H, o.s[1]); d->Wo = cdiv(s.W, o.s[2]);
+    d->Cout = L.geom.rows;
+    d->dT = s.T; d->dH = s.H; d->dW = s.W; d->dC = o.cin;
+  } else {
+    d->To = s.T; d->Ho = s.H; d->Wo = s.W;
+    d->Cout = o.cin;
+  }
+}
+
+static void fill_pool(const ivf_i3d* n, const Op& o, int b, ivf_pool3d_desc* d) {
+  const ActBuf& s = n->bufs[o.src];
+  const ActBuf& t = n->bufs[o.dst];
+  memset(d, 0, sizeof(*d));
+  d->B = b; d->Ti = s.T; d->Hi = s.H; d->Wi = s.W; d->C = s.C; d->in_ld = s.C; d->in_coff = 0;
+  d->To = t.T; d->Ho = t.H; d->Wo = t.W; d->out_ld = t.C; d->out_coff = 0;
+  d->kT = o.k[0]; d->kH = o.k[1]; d->kW = o.k[2]; d->sT = o.s[0]; d->sH = o.s[1]; d->sW = o.s[2];
+  d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
+}
+
+static int check_ready(const ivf_i3d* n, int b) {
+  IVF_CHECK_ARG(n != nullptr, "i3d: null handle");
+  IVF_CHECK_ARG(n->warena && n->ws, "i3d: ivf_i3d_bind has not been called");
+  IVF_CHECK_ARG(b > 0 && b <= n->cfg.B, "i3d: batch %d outside [1,%d]", b, n->cfg.B);
+  for (size_t i = 0; i < n->loaded.size(); ++i)
+    IVF_CHECK_ARG(n->loaded[i], "i3d: weights of unit %s not loaded", n->convs[i].name.c_str());
+  return IVF_OK;
+}
+
+static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream_t s) {
+  for (const Op& o : n->ops) {
+    if (o.type == Op::CONV) {
+      const ConvLayer& L = n->convs[o.conv];
+      ivf_conv3d_desc d;
+      fill_conv_fwd(n, o, b, &d);
+      IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off,
+                               n->warena + L.shift_off, nullptr, n->act(o.dst), s));
+    } else {
+      ivf_pool3d_desc d;
+      fill_pool(n, o, b, &d);
+      IVF_PROPAGATE(ivf_maxpool3d_fwd(&d, n->act(o.src), n->act(o.dst), n->at<unsigned char>(o.idx_off), s));
+    }
+  }
+  const ActBuf& f = n->bufs[n->feat_buf];
+  const ConvLayer& L = n->convs.back();
+  float* lg = n->at<float>(n->off_logits);
+  float* pr = n->at<float>(n->off_probs);
+  IVF_PROPAGATE(ivf_head_fwd(n->act(n->feat_buf), n->warena + L.wf_off, n->warena + L.shift_off,
+                             n->at<float>(n->off_pooled), lg, pr, b, f.T * f.H * f.W, f.C, n->cfg.num_classes,
+                             n->cfg.softmax, s));
+  size_t nb = (size_t)b * n->cfg.num_classes * sizeof(float);
+  if (logits) IVF_CHECK_HIP(hipMemcpyAsync(logits, lg, nb, hipMemcpyDeviceToDevice, s));
+  if (probs) IVF_CHECK_HIP(hipMemcpyAsync(probs, pr, nb, hipMemcpyDeviceToDevice, s));
+  return IVF_OK;
+}
+
+// backward-data from the head down to the channels-last input gradient
+static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout, float* score,
+                        hipStream_t s) {
+  const ActBuf& f = n->bufs[n->feat_buf];
+  const ConvLayer& Lh = n->convs.back();
+  IVF_PROPAGATE(ivf_head_bwd(n->act(n->feat_buf), n->warena + Lh.wf_off, n->at<float>(n->off_probs), target,
+                             dout, score, nullptr, n->grad(n->feat_buf), b, f.T * f.H * f.W, f.C,
+                             n->cfg.num_classes, n->cfg.softmax, 1, s));
+  for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
+    const Op& o = n->ops[i];
+    const float* gate = o.bwd_mask ? n->act(o.src) : nullptr;
+    if (o.type == Op::CONV) {
+      const ConvLayer& L = n->convs[o.conv];
+      ivf_conv3d_desc d;
+      fill_conv_bwd(n, o, b, &d);
+      IVF_PROPAGATE(ivf_conv3d(&d, n->grad(o.dst), n->warena + L.wb_off, nullptr, nullptr, gate,
+                               n->grad(o.src), s));
+    } else {
+      ivf_pool3d_desc d;
+      fill_pool(n, o, b, &d);
+      IVF_PROPAGATE(ivf_maxpool3d_bwd(&d, n->grad(o.dst), n->at<unsigned char>(o.idx_off), n->grad(o.src),
+                                      gate, o.bwd_accumulate, s));
+    }
+  }
+  return IVF_OK;
+}
+
+__global__ void ncthw_to_cl4_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int T,
+                                    int HW) {
+  size_t total = (size_t)B * T * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int px = i % HW;
+    int t = (i / HW) % T;
+    int b = i / ((size_t)HW * T);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) v[c] = x[((size_t)(b * C + c) * T + t) * HW + px];
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ void cl4_to_ncthw_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int C, int T,
+                                    int HW) {
+  size_t total = (size_t)B * C * T * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int px = i % HW;
+    int t = (i / HW) % T;
+    int c = (i / ((size_t)HW * T)) % C;
+    int b = i / ((size_t)HW * T * C);
+    x[i] = y[((size_t)(b * T + t) * HW + px) * 4 + c];
+  }
+}
+
+// per-clip reverse pairing for b masks (one thread per clip; see mask_ops.hip)
+__global__ void pairs_batched_kernel(const float* __restrict__ mask, int b, int T, float thresh,
+                                     int* __restrict__ partner, float* __restrict__ weight) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const float* m = mask + (size_t)i * T;
+  int* pr = partner + (size_t)i * T;
+  float* wt = weight + (size_t)i * T;
+  int start = -1;
+  for (int j = 0; j <= T; ++j) {
+    bool on = (j < T) && (m[j] > thresh);
+    if (j < T) { pr[j] = j; wt[j] = 0.f; }
+    if (on && start < 0) start = j;
+    if (!on && start >= 0) {
+      int len = j - start;
+      for (int u = 0; u < len / 2; ++u) {
+        int a = start + u, bb = start + len - 1 - u;
+        pr[a] = bb; pr[bb] = a; wt[a] = m[a]; wt[bb] = m[a];
+      }
+      start = -1;
+    }
+  }
+}
+
+__global__ void reverse_cl4_batched_kernel(const float* __restrict__ x, const int* __restrict__ partner,
+                                           const float* __restrict__ weight, float* __restrict__ p, int B,
+                                           int C, int T, int HW) {
+  size_t total = (size_t)B * T * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int px = i % HW;
+    int t = (i / HW) % T;
+    int b = i / ((size_t)HW * T);
+    int pt = partner[b * T + t];
+    float w = weight[b * T + t];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      float xv = x[((size_t)(b * C + c) * T + t) * HW + px];
+      if (pt != t) xv = (1.f - w) * xv + w * x[((size_t)(b * C + c) * T + pt) * HW + px];
+      v[c] = xv;
+    }
+    *reinterpret_cast<float4*>(p + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+static inline int grid_for(size_t total, int block = 256, int cap = 4096) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g > (size_t)cap ? cap : (g ? g : 1));
+}
+
+}  // namespace ivf
+
+extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
+  IVF_CHECK_ARG(cfg && out, "i3d_create: null pointer");
+  IVF_CHECK_ARG(cfg->B > 0 && cfg->C > 0 && cfg->C <= 4 && cfg->T > 0 && cfg->T <= 64 && cfg->H > 0 &&
+                    cfg->W > 0 && cfg->num_classes > 0,
+                "i3d_create: bad geometry (C<=4, T<=64)");
+  IVF_CHECK_ARG(cfg->stem_stride_t >= 1 && cfg->stem_stride_t <= 2 && cfg->pool4a_stride_t >= 1 &&
+                    cfg->pool4a_stride_t <= 2 && cfg->pool5a_stride_t >= 1 && cfg->pool5a_stride_t <= 2,
+                "i3d_create: temporal strides must be 1 or 2");
+  ivf_i3d* n = new ivf_i3d();
+  n->cfg = *cfg;
+  int rc = build_plan(n);
+  if (rc != IVF_OK) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return IVF_OK;
+}
+
+extern "C" void ivf_i3d_destroy(ivf_i3d_t* net) { delete net; }
+extern "C" size_t ivf_i3d_weights_bytes(const ivf_i3d_t* net) { return net ? net->weights_floats * 4 : 0; }
+extern "C" size_t ivf_i3d_workspace_bytes(const ivf_i3d_t* net) { return net ? net->ws_bytes : 0; }
+
+extern "C" int ivf_i3d_bind(ivf_i3d_t* net, void* weights_arena, void* workspace) {
+  IVF_CHECK_ARG(net && weights_arena && workspace, "i3d_bind: null pointer");
+  IVF_CHECK_ARG(((uintptr_t)weights_arena & 255) == 0 && ((uintptr_t)workspace & 255) == 0,
+                "i3d_bind: arenas must be 256-byte aligned");
+  net->warena = (float*)weights_arena;
+  net->ws = (char*)workspace;
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_num_convs(const ivf_i3d_t* net) { return net ? (int)net->convs.size() : 0; }
+
+extern "C" int ivf_i3d_conv_info(const ivf_i3d_t* net, int i, char* name64, int* cout, int* cin, int* kT,
+                                 int* kH, int* kW, int* has_bn) {
+  IVF_CHECK_ARG(net && i >= 0 && i < (int)net->convs.size(), "i3d_conv_info: bad index");
+  const ConvLayer& L = net->convs[i];
+  if (name64) { strncpy(name64, L.name.c_str(), 63); name64[63] = 0; }
+  if (cout) *cout = L.cout;
+  if (cin) *cin = L.cin;
+  if (kT) *kT = L.k[0];
+  if (kH) *kH = L.k[1];
+  if (kW) *kW = L.k[2];
+  if (has_bn) *has_bn = L.has_bn;
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_load_conv(ivf_i3d_t* net, int i, const float* w, const float* g, const float* be,
+                                 const float* mu, const float* var, const float* bias, float eps,
+                                 ivf_stream_t stream) {
+  IVF_CHECK_ARG(net && net->warena, "i3d_load_conv: bind first");
+  IVF_CHECK_ARG(i >= 0 && i < (int)net->convs.size() && w, "i3d_load_conv: bad index/null weight");
+  ConvLayer& L = net->convs[i];
+  hipStream_t s = (hipStream_t)stream;
+  float* A = net->warena;
+  if (L.name == "logits") {
+    IVF_CHECK_ARG(bias, "i3d_load_conv: logits unit needs its bias");
+    IVF_CHECK_HIP(hipMemcpyAsync(A + L.wf_off, w, L.wf_elems * 4, hipMemcpyDeviceToDevice, s));
+    IVF_CHECK_HIP(hipMemcpyAsync(A + L.shift_off, bias, (size_t)L.cout * 4, hipMemcpyDeviceToDevice, s));
+    net->loaded[i] = true;
+    return IVF_OK;
+  }
+  IVF_CHECK_ARG(g && be && mu && var, "i3d_load_conv: unit %s needs BatchNorm tensors", L.name.c_str());
+  IVF_PROPAGATE(ivf_bn_fold(g, be, mu, var, eps, A + L.scale_off, A + L.shift_off, L.cout, s));
+  IVF_PROPAGATE(ivf_conv3d_pack_fwd(w, A + L.wf_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1], L.k[2], s));
+  IVF_PROPAGATE(ivf_conv3d_pack_bwd(w, A + L.scale_off, A + L.wb_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1],
+                                    L.k[2], L.s[0], L.s[1], L.s[2], L.pad[0], L.pad[1], L.pad[2], &L.geom, s));
+  net->loaded[i] = true;
+  return IVF_OK;
+}
+
+extern "C" float* ivf_i3d_input_buffer(ivf_i3d_t* net) { return (net && net->ws) ? net->act(0) : nullptr; }
+extern "C" float* ivf_i3d_input_grad_buffer(ivf_i3d_t* net) { return (net && net->ws) ? net->grad(0) : nullptr; }
+
+extern "C" int ivf_i3d_forward_staged(ivf_i3d_t* net, int b, float* logits, float* probs,
+                                      ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  return run_forward(net, b, logits, probs, (hipStream_t)stream);
+}
+
+extern "C" int ivf_i3d_forward(ivf_i3d_t* net, const float* x, int b, float* logits, float* probs,
+                               ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(x, "i3d_forward: null clip");
+  const ivf_i3d_config& c = net->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ncthw_to_cl4_kernel, dim3(grid_for((size_t)b * c.T * c.H * c.W)), dim3(256), 0, s, x,
+                     net->act(0), b, c.C, c.T, c.H * c.W);
+  IVF_CHECK_LAUNCH();
+  return run_forward(net, b, logits, probs, s);
+}
+
+extern "C" int ivf_i3d_backward(ivf_i3d_t* net, int b, const int* target, const float* dout, float* score,
+                                float* dx, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(target || dout, "i3d_backward: need target or dout");
+  hipStream_t s = (hipStream_t)stream;
+  IVF_PROPAGATE(run_backward(net, b, target, dout, score, s));
+  if (dx) {
+    const ivf_i3d_config& c = net->cfg;
+    hipLaunchKernelGGL(cl4_to_ncthw_kernel, dim3(grid_for((size_t)b * c.C * c.T * c.H * c.W)), dim3(256), 0,
+                       s, net->grad(0), dx, b, c.C, c.T, c.H * c.W);
+    IVF_CHECK_LAUNCH();
+  }
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** ptr, int* T, int* H, int* W,
+                                int* C, int* ld) {
+  IVF_CHECK_ARG(net && name && net->ws, "i3d_endpoint: bad args / not bound");
+  for (size_t i = 0; i < net->bufs.size(); ++i) {
+    const ActBuf& b = net->bufs[i];
+    if (b.name == name) {
+      if (ptr) *ptr = net->act((int)i);
+      if (T) *T = b.T;
+      if (H) *H = b.H;
+      if (W) *W = b.W;
+      if (C) *C = b.C;
+      if (ld) *ld = b.C;
+      return IVF_OK;
+    }
+  }
+  set_error("i3d_endpoint: unknown endpoint '%s'", name);
+  return IVF_ERR_BAD_ARG;
+}
+
+extern "C" int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* target, float* raw_mask,
+                              float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr,
+                              float beta1, float beta2, float eps, int N, int first_step, float* traj,
+                              ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(x && target && raw_mask && exp_avg && exp_avg_sq, "i3d_search: null pointer");
+  IVF_CHECK_ARG(N >= 0 && first_step >= 1, "i3d_search: bad iteration counts");
+  const ivf_i3d_config& c = net->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = c.T, HW = c.H * c.W;
+  float* sig = net->at<float>(net->off_sig);
+  float* terms = net->at<float>(net->off_terms);
+  float* dreg = net->at<float>(net->off_dreg);
+  float* dsig = net->at<float>(net->off_dsig);
+  float* score = net->at<float>(net->off_score);
+  for (int it = 0; it < N; ++it) {
+    IVF_PROPAGATE(ivf_mask_reg(raw_mask, b, T, lam1, lam2, sig, terms, dreg, s));              // smth:198-200
+    IVF_PROPAGATE(ivf_freeze_fwd(x, sig, net->act(0), b, c.C, T, HW, 1, 4, s));                // smth:202
+    IVF_PROPAGATE(run_forward(net, b, nullptr, nullptr, s));                                    // smth:202-205
+    IVF_PROPAGATE(run_backward(net, b, target, nullptr, score, s));                             // smth:213
+    IVF_PROPAGATE(ivf_freeze_bwd(x, sig, net->grad(0), dsig, nullptr, b, c.C, T, HW, 1, 4,
+                                 net->at<void>(net->off_fbwd), s));
+    IVF_PROPAGATE(ivf_search_step(raw_mask, sig, dsig, dreg, terms, score, exp_avg, exp_avg_sq,
+                                  traj ? traj + (size_t)it * b * 4 : nullptr, b, T, first_step + it, lr,
+                                  beta1, beta2, eps, s));                                       // smth:207-214
+  }
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_perturbed_forward(ivf_i3d_t* net, const float* x, int b, const float* mask, int mode,
+                                         float* probs, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(x && mask && (mode == 0 || mode == 1), "i3d_perturbed_forward: bad args");
+  const ivf_i3d_config& c = net->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    IVF_PROPAGATE(ivf_freeze_fwd(x, mask, net->act(0), b, c.C, c.T, c.H * c.W, 1, 4, s));
+  } else {
+    int* partner = net->at<int>(net->off_pair);
+    float* weight = (float*)(partner + (size_t)c.B * c.T);
+    hipLaunchKernelGGL(pairs_batched_kernel, dim3(cdiv(b, 64)), dim3(64), 0, s, mask, b, c.T, 0.1f, partner,
+                       weight);
+    IVF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reverse_cl4_batched_kernel, dim3(grid_for((size_t)b * c.T * c.H * c.W)), dim3(256), 0,
+                       s, x, partner, weight, net->act(0), b, c.C, c.T, c.H * c.W);
+    IVF_CHECK_LAUNCH();
+  }
+  return run_forward(net, b, nullptr, probs, s);
+}
+
+extern "C" int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int* target, int per_frame,
+                               int out_h, int out_w, float* cam, float* probs, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(x && target && cam && out_h > 0 && out_w > 0, "i3d_gradcam: bad args");
+  const ivf_i3d_config& c = net->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  IVF_PROPAGATE(ivf_i3d_forward(net, x, b, nullptr, probs, s));
+  const ActBuf& f = net->bufs[net->feat_buf];
+  const ConvLayer& Lh = net->convs.back();
+  const int npos = f.T * f.H * f.W;
+  float* draw = net->at<float>(net->off_dfeat_raw);
+  // gradient of the (post-softmax) class score w.r.t. Mixed_5c, ungated (the hook of
+  // pytorch-grad-cam/grad-cam.py:50-51 sees the raw gradient)
+  IVF_PROPAGATE(ivf_head_bwd(net->act(net->feat_buf), net->warena + Lh.wf_off, net->at<float>(net->off_probs),
+                             target, nullptr, nullptr, nullptr, draw, b, npos, f.C, c.num_classes, c.softmax,
+                             0, s));
+  float* wts = net->at<float>(net->off_camw);
+  float* cm = net->at<float>(net->off_cam);
+  IVF_PROPAGATE(ivf_gradcam_reduce(net->act(net->feat_buf), draw, wts, cm, b, npos, f.C, s));
+  IVF_CHECK_ARG(c.T / f.T >= 1, "i3d_gradcam: clip shorter than the feature map");
+  return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, f.T, f.H, f.W, out_h, out_w,
+                                  c.T / f.T, per_frame, s);
+}

@@ -1,0 +1,56 @@
+// Shared host-side helpers for libivf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#include "../../include/ivf_hip.h"
+
+namespace ivf {
+
+void set_error(const char* fmt, ...);
+
+#define IVF_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::ivf::set_error(__VA_ARGS__);             \
+      return IVF_ERR_BAD_ARG;                    \
+    }                                            \
+  } while (0)
+
+#define IVF_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      ::ivf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                       __FILE__, __LINE__);                                        \
+      return IVF_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define IVF_CHECK_LAUNCH() IVF_CHECK_HIP(hipGetLastError())
+
+#define IVF_PROPAGATE(expr)      \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != IVF_OK) return rc_; \
+  } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// TF-'same' front padding along one dim (reference I3D_doubled.py:9-13, 29-34).
+static inline void same_pad(int n, int k, int s, int* front, int* back) {
+  int p = (n % s == 0) ? (k - s) : (k - (n % s));
+  if (p < 0) p = 0;
+  *front = p / 2;
+  *back = p - p / 2;
+}
+static inline int same_out(int n, int k, int s) {
+  int f, b;
+  same_pad(n, k, s, &f, &b);
+  return (n + f + b - k) / s + 1;
+}
+
+}  // namespace ivf

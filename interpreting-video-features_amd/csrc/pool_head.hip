@@ -1,0 +1,481 @@
+// Max-pool with TF-'same' zero padding (forward with arg-max record, backward as a
+// deterministic gather), the I3D classification head (global average pool + 1x1x1
+// logits + softmax) forward and backward, and the Grad-CAM reductions.
+// All HBM-bound, channels-last, 16-byte vector accesses over channels.
+//
+// Reference: MaxPool3dSamePadding (models/I3D_doubled.py:8-40), head
+// (I3D_doubled.py:360-380), GradCamVideo.__call__ (grad_cam_videos.py:85-140).
+#include "ivf_common.h"
+
+namespace ivf {
+
+struct PoolArgs {
+  int B, Ti, Hi, Wi, C, in_ld, in_coff;
+  int To, Ho, Wo, out_ld, out_coff;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+};
+
+// forward: scan the window in (kt,kh,kw) order over the ZERO-padded input
+// (I3D_doubled.py:36-39 pads with zeros, not -inf), first strict maximum wins
+// (torch max_pool3d semantics).  idx = flat tap of the winner (may be a pad cell).
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   unsigned char* __restrict__ idx, PoolArgs a) {
+  const int C4 = a.C >> 2;
+  size_t total = (size_t)a.B * a.To * a.Ho * a.Wo * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    size_t m = i / C4;
+    int wo = m % a.Wo;
+    size_t t1 = m / a.Wo;
+    int ho = t1 % a.Ho;
+    size_t t2 = t1 / a.Ho;
+    int to = t2 % a.To;
+    int b = t2 / a.To;
+    float best[4];
+    int bi[4];
+    bool first = true;
+    int tap = 0;
+    for (int kt = 0; kt < a.kT; ++kt) {
+      int ti = to * a.sT - a.pT + kt;
+      for (int kh = 0; kh < a.kH; ++kh) {
+        int hi = ho * a.sH - a.pH + kh;
+        for (int kw = 0; kw < a.kW; ++kw, ++tap) {
+          int wi = wo * a.sW - a.pW + kw;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
+              (unsigned)wi < (unsigned)a.Wi) {
+            v = *reinterpret_cast<const float4*>(
+                x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + 4 * c4);
+          }
+          float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (first || vv[q] > best[q] || vv[q] != vv[q]) {
+              best[q] = vv[q];
+              bi[q] = tap;
+            }
+          }
+          first = false;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + 4 * c4) =
+        make_float4(best[0], best[1], best[2], best[3]);
+    if (idx) {
+      uchar4 u = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+      *reinterpret_cast<uchar4*>(idx + m * a.C + 4 * c4) = u;
+    }
+  }
+}
+
+// backward: for every input cell sum dY of the windows whose recorded winner is
+// this cell.  dy has (out_ld, out_coff) geometry, dx has (in_ld, in_coff).
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   float* __restrict__ dx, const float* __restrict__ relu_mask,
+                                   int accumulate, PoolArgs a) {
+  const int C4 = a.C >> 2;
+  size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    size_t m = i / C4;
+    int wi = m % a.Wi;
+    size_t t1 = m / a.Wi;
+    int hi = t1 % a.Hi;
+    size_t t2 = t1 / a.Hi;
+    int ti = t2 % a.Ti;
+    int b = t2 / a.Ti;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows (to) with to*s - p <= ti <= to*s - p + k - 1
+    for (int kt = 0; kt < a.kT; ++kt) {
+      int num = ti + a.pT - kt;
+      if (num < 0 || num % a.sT) continue;
+      int to = num / a.sT;
+      if (to >= a.To) continue;
+      for (int kh = 0; kh < a.kH; ++kh) {
+        int nh = hi + a.pH - kh;
+        if (nh < 0 || nh % a.sH) continue;
+        int ho = nh / a.sH;
+        if (ho >= a.Ho) continue;
+        for (int kw = 0; kw < a.kW; ++kw) {
+          int nw = wi + a.pW - kw;
+          if (nw < 0 || nw % a.sW) continue;
+          int wo = nw / a.sW;
+          if (wo >= a.Wo) continue;
+          int tap = (kt * a.kH + kh) * a.kW + kw;
+          size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+          uchar4 u = *reinterpret_cast<const uchar4*>(idx + mo * a.C + 4 * c4);
+          float4 g = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + 4 * c4);
+          if (u.x == tap) acc[0] += g.x;
+          if (u.y == tap) acc[1] += g.y;
+          if (u.z == tap) acc[2] += g.z;
+          if (u.w == tap) acc[3] += g.w;
+        }
+      }
+    }
+    float* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
+    if (accumulate) {
+      float4 o = *reinterpret_cast<const float4*>(dst);
+      acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+    }
+    if (relu_mask) {
+      float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
+      if (!(k.x > 0.f)) acc[0] = 0.f;
+      if (!(k.y > 0.f)) acc[1] = 0.f;
+      if (!(k.z > 0.f)) acc[2] = 0.f;
+      if (!(k.w > 0.f)) acc[3] = 0.f;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// ---------------------------------------------------------------- head
+// One block per clip.  pooled[c] = mean over the npos feature cells;
+// logits[k] = bias[k] + sum_c pooled[c] W[k][c]; probs = softmax(logits).
+__global__ __launch_bounds__(256) void head_fwd_kernel(
+    const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ pooled_out, float* __restrict__ logits, float* __restrict__ probs, int npos,
+    int C, int K, int softmax) {
+  extern __shared__ float sm[];  // C pooled + K logits + 8 scratch
+  float* pooled = sm;
+  float* lg = sm + C;
+  float* red = lg + K;
+  const int b = blockIdx.x;
+  const float* f = feat + (size_t)b * npos * C;
+  const float inv = 1.f / (float)npos;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < npos; ++p) s += f[(size_t)p * C + c];
+    pooled[c] = s * inv;
+    if (pooled_out) pooled_out[(size_t)b * C + c] = s * inv;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = wave; k < K; k += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += pooled[c] * w[(size_t)k * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) {
+      s += bias ? bias[k] : 0.f;
+      lg[k] = s;
+      logits[(size_t)b * K + k] = s;
+    }
+  }
+  __syncthreads();
+  if (!probs) return;
+  if (!softmax) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) probs[(size_t)b * K + k] = lg[k];
+    return;
+  }
+  if (threadIdx.x == 0) {
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, lg[k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(lg[k] - mx);
+    red[0] = mx;
+    red[1] = s;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    probs[(size_t)b * K + k] = expf(lg[k] - red[0]) / red[1];
+}
+
+// backward to the feature map from an upstream gradient on the head output:
+// dout[b,:] if given, else one-hot at target[b] (score[b] = out[b,target[b]]).
+// softmax: dlogit[k] = p_k (dout_k - sum_j p_j dout_j); else dlogit = dout.
+// dpooled[c] = sum_k dlogit[k] W[k][c]; dfeat[b,pos,c] = dpooled[c] / npos, optionally
+// gated by (feat > 0) for the ReLU below.
+__global__ __launch_bounds__(256) void head_bwd_kernel(
+    const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ probs,
+    const int* __restrict__ target, const float* __restrict__ dout, float* __restrict__ score,
+    float* __restrict__ dpooled_out, float* __restrict__ dfeat, int npos, int C, int K, int softmax,
+    int gate) {
+  extern __shared__ float sm[];
+  float* dl = sm;        // K
+  float* dp = sm + K;    // C
+  __shared__ float dot;
+  const int b = blockIdx.x;
+  const int t = target ? target[b] : -1;
+  const float* pr = probs + (size_t)b * K;
+  if (threadIdx.x == 0) {
+    if (score && target) score[b] = pr[t];
+    float s = 0.f;
+    if (softmax) {
+      if (dout) {
+        for (int k = 0; k < K; ++k) s += pr[k] * dout[(size_t)b * K + k];
+      } else {
+        s = pr[t];
+      }
+    }
+    dot = s;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float d = dout ? dout[(size_t)b * K + k] : ((k == t) ? 1.f : 0.f);
+    dl[k] = softmax ? pr[k] * (d - dot) : d;
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)npos;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += dl[k] * w[(size_t)k * C + c];
+    dp[c] = s * inv;
+    if (dpooled_out) dpooled_out[(size_t)b * C + c] = s;
+  }
+  __syncthreads();
+  if (!dfeat) return;
+  const float* f = feat + (size_t)b * npos * C;
+  float* df = dfeat + (size_t)b * npos * C;
+  for (int i = threadIdx.x; i < npos * C; i += blockDim.x) {
+    int c = i % C;
+    float v = dp[c];
+    if (gate && !(f[i] > 0.f)) v = 0.f;
+    df[i] = v;
+  }
+}
+
+__global__ void argmax_kernel(const float* __restrict__ probs, int b, int K, int* __restrict__ target) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const float* p = probs + (size_t)i * K;
+  int best = 0;
+  float bv = p[0];
+  for (int k = 1; k < K; ++k)
+    if (p[k] > bv) { bv = p[k]; best = k; }   // first maximum, as np.argmax
+  target[i] = best;
+}
+
+// ---------------------------------------------------------------- Grad-CAM
+// weights[b,k] = mean over positions of grad[b,pos,k]     (grad_cam_videos.py:98)
+__global__ void gradcam_weights_kernel(const float* __restrict__ grad, float* __restrict__ wts, int npos,
+                                       int C, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i % C;
+  float s = 0.f;
+  for (int p = 0; p < npos; ++p) s += grad[((size_t)b * npos + p) * C + c];
+  wts[i] = s / (float)npos;
+}
+
+// cam[b,pos] = max(sum_k w[b,k] feat[b,pos,k], 0)          (grad_cam_videos.py:101-110)
+// one wave per position, lanes stride over channels
+__global__ __launch_bounds__(256) void gradcam_cam_kernel(const float* __restrict__ feat,
+                                                          const float* __restrict__ wts,
+                                                          float* __restrict__ cam, int npos, int C,
+                                                          int B) {
+  int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (gw >= B * npos) return;
+  int b = gw / npos;
+  const float* f = feat + (size_t)gw * C;
+  const float* w = wts + (size_t)b * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += w[c] * f[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) cam[gw] = fmaxf(s, 0.f);
+}
+
+// OpenCV INTER_LINEAR sampling rule for float32 (cv2.resize call site
+// grad_cam_videos.py:119): half-pixel centres, clamped source index.
+__device__ __forceinline__ void lin_coeff(int d, float scale, int src, int* i0, int* i1, float* f) {
+  float fx = ((float)d + 0.5f) * scale - 0.5f;
+  int s = (int)floorf(fx);
+  float fr = fx - (float)s;
+  if (s < 0) { fr = 0.f; s = 0; }
+  if (s >= src - 1) { fr = 0.f; s = src - 1; }
+  *i0 = s;
+  *i1 = min(s + 1, src - 1);
+  *f = fr;
+}
+
+__device__ __forceinline__ float bilinear_at(const float* src, int sh, int sw, int y, int x, float sy,
+                                             float sx) {
+  int y0, y1, x0, x1;
+  float fy, fx;
+  lin_coeff(y, sy, sh, &y0, &y1, &fy);
+  lin_coeff(x, sx, sw, &x0, &x1, &fx);
+  float top = src[y0 * sw + x0] * (1.f - fx) + src[y0 * sw + x1] * fx;
+  float bot = src[y1 * sw + x0] * (1.f - fx) + src[y1 * sw + x1] * fx;
+  return top * (1.f - fy) + bot * fy;
+}
+
+// pass 1: per (b, slice) min / max of the resized map
+__global__ __launch_bounds__(256) void cam_minmax_kernel(const float* __restrict__ cam,
+                                                         float* __restrict__ mm, int sh, int sw, int H,
+                                                         int W) {
+  const float* src = cam + (size_t)blockIdx.x * sh * sw;
+  float sy = (float)sh / (float)H, sx = (float)sw / (float)W;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+    float v = bilinear_at(src, sh, sw, i / W, i % W, sy, sx);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  __shared__ float smn[4], smx[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_down(mn, o, 64));
+    mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[blockIdx.x * 2 + 0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mm[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+
+// pass 2: resize, subtract min, divide by max(x - min), repeat `step` frames
+// (grad_cam_videos.py:121-138).  per_frame: statistics of the slice's own block,
+// else of the whole clip.  0/0 -> NaN exactly as numpy does.
+__global__ __launch_bounds__(256) void cam_resize_norm_kernel(const float* __restrict__ cam,
+                                                              const float* __restrict__ mm,
+                                                              float* __restrict__ out, int nslice, int sh,
+                                                              int sw, int H, int W, int step,
+                                                              int per_frame) {
+  const int bs = blockIdx.x;  // (b, slice)
+  const int b = bs / nslice, sl = bs % nslice;
+  const float* src = cam + (size_t)bs * sh * sw;
+  float mn, mx;
+  if (per_frame) {
+    mn = mm[bs * 2];
+    mx = mm[bs * 2 + 1];
+  } else {
+    mn = INFINITY;
+    mx = -INFINITY;
+    for (int i = 0; i < nslice; ++i) {
+      mn = fminf(mn, mm[(b * nslice + i) * 2]);
+      mx = fmaxf(mx, mm[(b * nslice + i) * 2 + 1]);
+    }
+  }
+  const float den = mx - mn;
+  float sy = (float)sh / (float)H, sx = (float)sw / (float)W;
+  float* dst = out + ((size_t)b * nslice + sl) * step * H * W;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+    float v = (bilinear_at(src, sh, sw, i / W, i % W, sy, sx) - mn) / den;
+    for (int r = 0; r < step; ++r) dst[(size_t)r * H * W + i] = v;
+  }
+}
+
+static inline int grid_for(size_t total, int block = 256, int cap = 4096) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g > (size_t)cap ? cap : (g ? g : 1));
+}
+
+static int check_pool(const ivf_pool3d_desc* d) {
+  IVF_CHECK_ARG(d, "pool: null descriptor");
+  IVF_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0,
+                "pool: bad dims");
+  IVF_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->in_ld % 4 == 0 && d->in_coff % 4 == 0 &&
+                    d->out_ld % 4 == 0 && d->out_coff % 4 == 0,
+                "pool: channel counts/offsets must be multiples of 4");
+  IVF_CHECK_ARG(d->in_coff + d->C <= d->in_ld && d->out_coff + d->C <= d->out_ld,
+                "pool: channel window outside ld");
+  IVF_CHECK_ARG(d->kT * d->kH * d->kW <= 255, "pool: window too large for uint8 arg-max");
+  return IVF_OK;
+}
+
+static PoolArgs to_args(const ivf_pool3d_desc* d) {
+  PoolArgs a;
+  a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.in_ld = d->in_ld;
+  a.in_coff = d->in_coff; a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.out_ld = d->out_ld;
+  a.out_coff = d->out_coff; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.sT = d->sT; a.sH = d->sH;
+  a.sW = d->sW; a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
+  return a;
+}
+
+}  // namespace ivf
+
+using namespace ivf;
+
+extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float* y,
+                                 unsigned char* argmax, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_pool(d));
+  IVF_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
+  PoolArgs a = to_args(d);
+  size_t total = (size_t)a.B * a.To * a.Ho * a.Wo * (a.C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     argmax, a);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, const unsigned char* argmax,
+                                 float* dx, const float* relu_mask, int accumulate,
+                                 ivf_stream_t stream) {
+  IVF_PROPAGATE(check_pool(d));
+  IVF_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null pointer");
+  PoolArgs a = to_args(d);
+  size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy,
+                     argmax, dx, relu_mask, accumulate, a);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_head_fwd(const float* feat, const float* w, const float* bias, float* pooled,
+                            float* logits, float* probs, int B, int npos, int C, int K, int softmax,
+                            ivf_stream_t stream) {
+  IVF_CHECK_ARG(feat && w && logits, "head_fwd: null pointer");
+  IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K + 8) * 4 <= 64 * 1024,
+                "head_fwd: bad dims");
+  size_t shm = (size_t)(C + K + 8) * sizeof(float);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, feat, w, bias, pooled,
+                     logits, probs, npos, C, K, softmax);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream) {
+  IVF_CHECK_ARG(probs && target && b > 0 && K > 0, "argmax: bad args");
+  hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(b, 64)), dim3(64), 0, (hipStream_t)stream, probs, b, K, target);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_head_bwd(const float* feat, const float* w, const float* probs, const int* target,
+                            const float* dout, float* score, float* dpooled, float* dfeat, int B,
+                            int npos, int C, int K, int softmax, int gate_relu, ivf_stream_t stream) {
+  IVF_CHECK_ARG(w && probs && (target || dout), "head_bwd: need probs, w and target or dout");
+  IVF_CHECK_ARG(!dfeat || feat, "head_bwd: feat required with dfeat");
+  IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K) * 4 <= 64 * 1024,
+                "head_bwd: bad dims");
+  size_t shm = (size_t)(C + K) * sizeof(float);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, feat, w, probs,
+                     target, dout, score, dpooled, dfeat, npos, C, K, softmax, gate_relu);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_gradcam_reduce(const float* feat, const float* grad, float* weights, float* cam,
+                                  int B, int npos, int C, ivf_stream_t stream) {
+  IVF_CHECK_ARG(feat && grad && weights && cam && B > 0 && npos > 0 && C > 0, "gradcam_reduce: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gradcam_weights_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, grad, weights, npos,
+                     C, B);
+  IVF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gradcam_cam_kernel, dim3(cdiv((size_t)B * npos * 64, 256)), dim3(256), 0, s, feat,
+                     weights, cam, npos, C, B);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_cam_resize_normalise(const float* cam, float* out, float* minmax_ws, int B, int nslice,
+                                        int sh, int sw, int H, int W, int step, int per_frame,
+                                        ivf_stream_t stream) {
+  IVF_CHECK_ARG(cam && out && minmax_ws, "cam_resize: null pointer");
+  IVF_CHECK_ARG(B > 0 && nslice > 0 && sh > 0 && sw > 0 && H > 0 && W > 0 && step > 0, "cam_resize: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cam_minmax_kernel, dim3(B * nslice), dim3(256), 0, s, cam, minmax_ws, sh, sw, H, W);
+  IVF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cam_resize_norm_kernel, dim3(B * nslice), dim3(256), 0, s, cam, minmax_ws, out,
+                     nslice, sh, sw, H, W, step, per_frame);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}

@@ -1,0 +1,204 @@
+"""Host-side owner of one libivf_hip network plan (I3D or CLSTM_4).
+
+Holds the two device arenas (weights, workspace) as torch tensors -- PyTorch is
+the allocator, nothing more -- and exposes the plan's entry points with torch
+tensors in/out.  Everything that computes is in csrc/*.hip.
+"""
+import ctypes
+from ctypes import byref, c_char, c_int, c_void_p
+
+import numpy as np
+import torch
+
+import ivf_arch as arch
+import ivf_lib as L
+
+
+def _arena(nbytes, device):
+    # torch's caching allocator returns >=512-byte aligned blocks
+    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    assert t.data_ptr() % 256 == 0
+    return t
+
+
+class I3DEngine:
+    """Plan + arenas for `models.I3D_doubled{,_kth}.Model` on `max_batch` clips of
+    geometry [C,T,H,W] (reference Model.forward, I3D_doubled.py:351-380)."""
+
+    def __init__(self, num_classes, clip_shape, max_batch=1, stride_mod_layers="", last_stride=1,
+                 head_hw=(7, 7), head_time_base=2, softmax=True, device=None):
+        L.require_gpu()
+        self.device = torch.device(device if device is not None else "cuda")
+        C, T, H, W = clip_shape
+        sml = arch.parse_stride_mod(stride_mod_layers)
+        cfg = L.I3DConfig()
+        cfg.B, cfg.C, cfg.T, cfg.H, cfg.W = int(max_batch), C, T, H, W
+        cfg.num_classes = int(num_classes)
+        cfg.stem_stride_t = arch.temporal_stride('Conv3d_1a_7x7', sml, last_stride)
+        cfg.pool4a_stride_t = arch.temporal_stride('MaxPool3d_4a_3x3', sml, last_stride)
+        cfg.pool5a_stride_t = arch.temporal_stride('MaxPool3d_5a_2x2', sml, last_stride)
+        cfg.head_kt = arch.head_time_kernel(sml, last_stride, head_time_base)
+        cfg.head_kh, cfg.head_kw = head_hw
+        cfg.softmax = 1 if softmax else 0
+        self.cfg = cfg
+        self.clip_shape = (C, T, H, W)
+        self.max_batch = int(max_batch)
+        self.K = int(num_classes)
+        self._h = c_void_p()
+        L.check(L.lib().ivf_i3d_create(byref(cfg), byref(self._h)))
+        with torch.cuda.device(self.device):
+            self._weights = _arena(L.lib().ivf_i3d_weights_bytes(self._h), self.device)
+            self._ws = _arena(L.lib().ivf_i3d_workspace_bytes(self._h), self.device)
+        L.check(L.lib().ivf_i3d_bind(self._h, L.ptr(self._weights), L.ptr(self._ws)))
+        self.unit_names = []
+        for i in range(L.lib().ivf_i3d_num_convs(self._h)):
+            name = ctypes.create_string_buffer(64)
+            L.check(L.lib().ivf_i3d_conv_info(self._h, i, name, None, None, None, None, None, None))
+            self.unit_names.append(name.value.decode())
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            L.lib().ivf_i3d_destroy(h)
+            self._h = c_void_p()
+
+    @property
+    def workspace_bytes(self):
+        return self._ws.numel()
+
+    # -------------------------------------------------------------- weights
+    def load_state_dict(self, sd, bn_eps=1e-3):
+        """sd: reference key scheme, optional 'module.' prefix."""
+        def get(key):
+            for k in (key, "module." + key):
+                if k in sd:
+                    v = sd[k]
+                    if isinstance(v, np.ndarray):
+                        v = torch.from_numpy(v)
+                    return L.f32c(v.detach().to(self.device))
+            raise KeyError(f"state_dict is missing '{key}'")
+        keep = []
+        with torch.cuda.device(self.device):
+            for i, name in enumerate(self.unit_names):
+                w = get(f"{name}.conv3d.weight")
+                if name == "logits":
+                    bias = get("logits.conv3d.bias")
+                    keep += [w, bias]
+                    L.check(L.lib().ivf_i3d_load_conv(self._h, i, L.ptr(w), None, None, None, None,
+                                                      L.ptr(bias), bn_eps, L.stream()))
+                else:
+                    g, b = get(f"{name}.bn.weight"), get(f"{name}.bn.bias")
+                    m, v = get(f"{name}.bn.running_mean"), get(f"{name}.bn.running_var")
+                    keep += [w, g, b, m, v]
+                    L.check(L.lib().ivf_i3d_load_conv(self._h, i, L.ptr(w), L.ptr(g), L.ptr(b), L.ptr(m),
+                                                      L.ptr(v), None, bn_eps, L.stream()))
+            torch.cuda.current_stream().synchronize()   # sources may be freed after this
+
+    # -------------------------------------------------------------- helpers
+    def _clip(self, x):
+        L.require_gpu(x)
+        x = L.f32c(x)
+        if x.dim() != 5 or tuple(x.shape[1:]) != self.clip_shape:
+            raise L.IvfError(f"clip batch must be [b,{','.join(map(str, self.clip_shape))}], got {tuple(x.shape)}")
+        if x.shape[0] > self.max_batch:
+            raise L.IvfError(f"batch {x.shape[0]} exceeds the plan's maximum {self.max_batch}")
+        return x
+
+    def _targets(self, target, b):
+        t = torch.as_tensor(target, device=self.device).to(torch.int32).reshape(-1).contiguous()
+        if t.numel() != b:
+            raise L.IvfError(f"need {b} targets, got {t.numel()}")
+        return t
+
+    # -------------------------------------------------------------- entry points
+    def forward(self, x, want_logits=False):
+        x = self._clip(x)
+        b = x.shape[0]
+        probs = torch.empty(b, self.K, device=self.device)
+        logits = torch.empty(b, self.K, device=self.device) if want_logits else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_forward(self._h, L.ptr(x), b, L.ptr(logits), L.ptr(probs), L.stream()))
+        return (probs, logits) if want_logits else probs
+
+    def backward(self, b, target=None, dout=None, want_dx=True):
+        """Backward-data of the last forward.  Returns (score [b] or None, dx NCTHW or None)."""
+        C, T, H, W = self.clip_shape
+        tgt = self._targets(target, b) if target is not None else None
+        dout = L.f32c(dout) if dout is not None else None
+        score = torch.empty(b, device=self.device) if tgt is not None else None
+        dx = torch.empty(b, C, T, H, W, device=self.device) if want_dx else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_backward(self._h, b, L.ptr(tgt), L.ptr(dout), L.ptr(score), L.ptr(dx),
+                                             L.stream()))
+        return score, dx
+
+    def endpoint(self, name, b):
+        """Activation of the last forward as an NCTHW torch tensor (copy)."""
+        p = c_void_p()
+        T, H, W, C, ld = c_int(), c_int(), c_int(), c_int(), c_int()
+        L.check(L.lib().ivf_i3d_endpoint(self._h, name.encode(), byref(p), byref(T), byref(H), byref(W),
+                                         byref(C), byref(ld)))
+        off = p.value - self._ws.data_ptr()
+        n = b * T.value * H.value * W.value * ld.value
+        flat = self._ws[off:off + 4 * n].view(torch.float32)
+        return flat.view(b, T.value, H.value, W.value, ld.value)[..., :C.value].permute(0, 4, 1, 2, 3).contiguous()
+
+    def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
+               state=None, want_traj=True):
+        """N iterations of the hot loop (smth:193-214) on b clips.  raw_mask [b,T] is
+        updated in place; state = (exp_avg, exp_avg_sq, steps_done) continues a search."""
+        x = self._clip(x)
+        b = x.shape[0]
+        T = self.clip_shape[1]
+        tgt = self._targets(target, b)
+        L.require_gpu(raw_mask)
+        if raw_mask.dtype != torch.float32 or not raw_mask.is_contiguous() or tuple(raw_mask.shape) != (b, T):
+            raise L.IvfError("raw_mask must be a contiguous float32 [b,T] tensor")
+        if state is None:
+            state = (torch.zeros_like(raw_mask), torch.zeros_like(raw_mask), 0)
+        m, v, done = state
+        traj = torch.empty(N, b, 4, device=self.device) if want_traj else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_search(self._h, L.ptr(x), b, L.ptr(tgt), L.ptr(raw_mask), L.ptr(m), L.ptr(v),
+                                           lam1, lam2, lr, betas[0], betas[1], eps, int(N), done + 1,
+                                           L.ptr(traj), L.stream()))
+        return traj, (m, v, done + int(N))
+
+    def perturbed_forward(self, x, mask, mode="freeze"):
+        x = self._clip(x)
+        b = x.shape[0]
+        mask = L.f32c(mask.to(self.device))
+        if tuple(mask.shape) != (b, self.clip_shape[1]):
+            raise L.IvfError("mask must be [b,T]")
+        probs = torch.empty(b, self.K, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_perturbed_forward(self._h, L.ptr(x), b, L.ptr(mask),
+                                                      0 if mode == "freeze" else 1, L.ptr(probs), L.stream()))
+        return probs
+
+    def argmax(self, probs):
+        b = probs.shape[0]
+        t = torch.empty(b, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_argmax(L.ptr(L.f32c(probs)), b, probs.shape[1], L.ptr(t), L.stream()))
+        return t
+
+    def gradcam(self, x, target=None, per_frame=True, out_hw=None):
+        """GradCamVideo for b clips: (cam [b,T,H,W], probs [b,K])."""
+        x = self._clip(x)
+        b = x.shape[0]
+        C, T, H, W = self.clip_shape
+        oh, ow = out_hw if out_hw is not None else (H, W)
+        if target is None:
+            target = self.argmax(self.forward(x))
+        tgt = self._targets(target, b)
+        p = c_void_p()
+        Tf = c_int()
+        L.check(L.lib().ivf_i3d_endpoint(self._h, b"Mixed_5c", byref(p), byref(Tf), None, None, None, None))
+        frames = Tf.value * (T // Tf.value)
+        cam = torch.empty(b, frames, oh, ow, device=self.device)
+        probs = torch.empty(b, self.K, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_gradcam(self._h, L.ptr(x), b, L.ptr(tgt), 1 if per_frame else 0, oh, ow,
+                                            L.ptr(cam), L.ptr(probs), L.stream()))
+        return cam, probs

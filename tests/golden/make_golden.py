@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE modules on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to
+the GPU box):  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Inputs and weights come from `ivf_recipe` (hash recipe), so the fixtures hold
+only small outputs / sampled entries; tests regenerate the inputs.  The one
+stand-in is `cv2.resize` (OpenCV is absent here): it is bound to
+oracle.gradcam_ref.resize_bilinear, so the Grad-CAM fixture pins everything
+except the resize rule itself (recorded as "parity unpinned" for that step).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference/video_features_pytorch'
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'interpreting-video-features_amd'))
+sys.path.insert(0, os.path.join(REF, 'pytorch-grad-cam'))
+sys.path.insert(0, REF)          # reference `mask`, `models` win over ours
+
+import ivf_recipe as R                                   # noqa: E402
+from oracle import gradcam_ref                           # noqa: E402
+
+cv2 = types.ModuleType('cv2')
+cv2.resize = lambda img, dsize: gradcam_ref.resize_bilinear(img, dsize[0], dsize[1])
+sys.modules['cv2'] = cv2
+for n in ('torchvision', 'torchvision.models', 'torchvision.utils'):
+    sys.modules[n] = types.ModuleType(n)
+sys.modules['torchvision'].models = sys.modules['torchvision.models']
+sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+
+import mask as ref_mask                                  # noqa: E402
+from models import I3D_doubled, I3D_doubled_kth, CLSTM_4  # noqa: E402
+import grad_cam_videos as ref_gc                         # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def sample_idx(key, n, count=1024):
+    u = R.uniform(key, (count,), 0.0, 1.0)
+    return np.minimum((u.astype(np.float64) * n).astype(np.int64), n - 1)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print('wrote', path, {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+# ---------------------------------------------------------------- mask ops
+def gen_mask_ops():
+    out = {}
+    for T in (16, 32):
+        x = torch.from_numpy(R.uniform(f'g/freeze/x{T}', (2, 3, T, 12, 20), 0, 255)).requires_grad_()
+        m = torch.from_numpy(R.uniform(f'g/freeze/m{T}', (T,), 0, 1)).requires_grad_()
+        g = torch.from_numpy(R.uniform(f'g/freeze/g{T}', (2, 3, T, 12, 20), -1, 1))
+        p = ref_mask.perturb_sequence(x, m, 'freeze')
+        (p * g).sum().backward()
+        out[f'freeze{T}_p'] = p.detach().numpy()
+        out[f'freeze{T}_dm'] = m.grad.numpy()
+        out[f'freeze{T}_dx'] = x.grad.numpy()
+    # reverse: odd/even runs, at the ends, threshold exactly 0.1
+    rev_masks = {
+        'even_mid': [0, 0, 0.9, 0.8, 0.7, 0.6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        'odd_mid': [0, 0, 0.9, 0.8, 0.7, 0.6, 0.5, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        'ends': [0.3, 0.4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.6, 0.7, 0.8],
+        'thresh': [0.1, 0.1000001, 0.2, 0.1, 0.5, 0.5, 0.5, 0.1, 0, 0, 0.11, 0.12, 0.13, 0.14, 0.1, 0.9],
+        'all_on': [0.5] * 16,
+        'all_off': [0.05] * 16,
+        'single': [0, 0, 0, 0, 0.7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    }
+    x = torch.from_numpy(R.uniform('g/reverse/x', (2, 3, 16, 6, 10), 0, 255))
+    for k, mv in rev_masks.items():
+        m = torch.tensor(mv, dtype=torch.float32)
+        out[f'rev_{k}_mask'] = m.numpy()
+        out[f'rev_{k}_p'] = ref_mask.perturb_sequence(x, m, 'reverse').numpy()
+        subs = ref_mask.find_submasks_from_mask(m, 0.1)
+        flat = [-1]
+        for s in subs:
+            flat += s + [-1]
+        out[f'rev_{k}_subs'] = np.array(flat, dtype=np.int64)
+    # snap
+    m = torch.from_numpy(R.uniform('g/snap/m', (16,), 0, 1))
+    m[3] = 0.5
+    out['snap_in'] = m.numpy().copy()
+    xs = torch.from_numpy(R.uniform('g/snap/x', (1, 3, 16, 4, 4), 0, 255))
+    out['snap_p'] = ref_mask.perturb_sequence(xs, m, 'freeze', snap_values=True).numpy()
+    out['snap_out'] = m.numpy().copy()
+    # tv norm + grad
+    tv_cases = {
+        'rand16': R.uniform('g/tv/rand16', (16,), 0, 1),
+        'rand32': R.uniform('g/tv/rand32', (32,), 0, 1),
+        'mono': np.linspace(0.05, 0.95, 16, dtype=np.float32),
+        'near_const': (0.5 + 1e-3 * R.uniform('g/tv/nc', (16,), -1, 1)).astype(np.float32),
+        'sig_pm5': 1 / (1 + np.exp(-np.array([-5] * 4 + [5] * 8 + [-5] * 4, dtype=np.float32))),
+        'const': np.full(16, 0.25, dtype=np.float32),
+    }
+    for k, v in tv_cases.items():
+        m = torch.from_numpy(v.astype(np.float32)).requires_grad_()
+        tv = ref_mask.calc_tv_norm(m, 3, 3)
+        tv.backward()
+        out[f'tv_{k}_in'] = v.astype(np.float32)
+        out[f'tv_{k}_val'] = tv.detach().numpy()
+        out[f'tv_{k}_grad'] = m.grad.numpy()
+    # Adam: torch.optim.Adam(lr=0.2) on a fixed gradient sequence (smth:191,212-214)
+    p = torch.from_numpy(R.uniform('g/adam/p', (16,), -5, 5)).requires_grad_()
+    grads = R.uniform('g/adam/g', (12, 16), -1e-2, 1e-2)
+    opt = torch.optim.Adam([p], lr=0.2)
+    traj = [p.detach().numpy().copy()]
+    for g in grads:
+        opt.zero_grad()
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        traj.append(p.detach().numpy().copy())
+    out['adam_traj'] = np.array(traj)
+    # full regulariser loss + grad through sigmoid (smth:198-200)
+    tm = torch.from_numpy(R.uniform('g/reg/tm', (16,), -5, 5)).requires_grad_()
+    mc = torch.sigmoid(tm)
+    loss = 0.01 * torch.sum(torch.abs(mc)) + 0.02 * ref_mask.calc_tv_norm(mc, 3, 3)
+    loss.backward()
+    out['reg_loss'] = loss.detach().numpy()
+    out['reg_grad'] = tm.grad.numpy()
+    save('mask_ops', **out)
+
+
+# ---------------------------------------------------------------- layer units
+def gen_units():
+    out = {}
+    unit_cases = {  # name: (cin, cout, k, stride, in T,H,W)
+        'k1': (24, 40, (1, 1, 1), (1, 1, 1), (3, 5, 6)),
+        'k3': (8, 12, (3, 3, 3), (1, 1, 1), (4, 7, 9)),
+        'k3_c16': (16, 48, (3, 3, 3), (1, 1, 1), (2, 7, 7)),
+        'k7s2_even': (3, 16, (7, 7, 7), (2, 2, 2), (8, 16, 18)),
+        'k7s2_odd': (3, 16, (7, 7, 7), (2, 2, 2), (7, 15, 17)),
+        'k7s1t': (3, 8, (7, 7, 7), (1, 2, 2), (6, 12, 12)),
+    }
+    for name, (cin, cout, k, s, thw) in unit_cases.items():
+        u = I3D_doubled.Unit3D(cin, cout, kernel_shape=list(k), stride=s, name=name).eval()
+        sd = {
+            'conv3d.weight': R.uniform(f'g/unit/{name}/w', (cout, cin) + k, -0.2, 0.2),
+            'bn.weight': R.uniform(f'g/unit/{name}/g', (cout,), 0.5, 1.5),
+            'bn.bias': R.uniform(f'g/unit/{name}/b', (cout,), -0.3, 0.3),
+            'bn.running_mean': R.uniform(f'g/unit/{name}/m', (cout,), -0.3, 0.3),
+            'bn.running_var': R.uniform(f'g/unit/{name}/v', (cout,), 0.5, 1.5),
+            'bn.num_batches_tracked': np.zeros((), np.int64),
+        }
+        u.load_state_dict(R.to_torch(sd))
+        x = torch.from_numpy(R.uniform(f'g/unit/{name}/x', (2, cin) + thw, -1, 1)).requires_grad_()
+        y = u(x)
+        g = torch.from_numpy(R.uniform(f'g/unit/{name}/gy', tuple(y.shape), -1, 1))
+        (y * g).sum().backward()
+        out[f'unit_{name}_y'] = y.detach().numpy()
+        out[f'unit_{name}_dx'] = x.grad.numpy()
+    pool_cases = {  # name: (k, s, in T,H,W)
+        'p133': ((1, 3, 3), (1, 2, 2), (3, 8, 10)),
+        'p133_odd': ((1, 3, 3), (1, 2, 2), (3, 7, 9)),
+        'p333s2': ((3, 3, 3), (2, 2, 2), (4, 8, 8)),
+        'p333s2_odd': ((3, 3, 3), (2, 2, 2), (5, 15, 7)),
+        'p222': ((2, 2, 2), (2, 2, 2), (4, 6, 8)),
+        'p222_odd': ((2, 2, 2), (2, 2, 2), (3, 7, 5)),
+        'p333s1': ((3, 3, 3), (1, 1, 1), (3, 5, 6)),
+        'p333s1t1': ((3, 3, 3), (1, 2, 2), (4, 8, 8)),
+    }
+    for name, (k, s, thw) in pool_cases.items():
+        mp = I3D_doubled.MaxPool3dSamePadding(kernel_size=list(k), stride=s, padding=0)
+        xv = R.uniform(f'g/pool/{name}/x', (2, 6) + thw, -1, 1)
+        xv = np.maximum(xv, 0)   # post-ReLU like: many exact-zero ties incl. vs the zero padding
+        x = torch.from_numpy(xv).requires_grad_()
+        y = mp(x)
+        g = torch.from_numpy(R.uniform(f'g/pool/{name}/gy', tuple(y.shape), -1, 1))
+        (y * g).sum().backward()
+        out[f'pool_{name}_y'] = y.detach().numpy()
+        out[f'pool_{name}_dx'] = x.grad.numpy()
+    save('units', **out)
+
+
+# ---------------------------------------------------------------- whole I3D
+def _i3d(kth=False, T=16, softmax=1):
+    if kth:
+        m = I3D_doubled_kth.Model(6, last_stride=1, stride_mod_layers="", finalTimeLength=T // 8,
+                                  softMax=softmax).eval()
+        sd = R.i3d_state_dict(num_classes=6, tag='i3d_kth')
+    else:
+        m = I3D_doubled.Model(174, last_stride=1, stride_mod_layers="", softMax=softmax).eval()
+        sd = R.i3d_state_dict(num_classes=174)
+    m.load_state_dict(R.to_torch(sd))
+    return m
+
+
+def gen_i3d():
+    out = {}
+    for tag, kth, shape in (('s16', False, (3, 16, 224, 224)), ('k32', True, (3, 32, 120, 160))):
+        m = _i3d(kth, T=shape[1])
+        x = torch.from_numpy(R.clip(7, *shape))[None].requires_grad_()
+        acts = {}
+        hooks = [m._modules[n].register_forward_hook(
+            (lambda n: (lambda mod, i, o: acts.__setitem__(n, o)))(n))
+            for n in I3D_doubled.Model.VALID_ENDPOINTS if n in m._modules]
+        m.softMax = False
+        with torch.no_grad():
+            logits = m(x)
+        m.softMax = 1
+        y = m(x)
+        for h in hooks:
+            h.remove()
+        target = int(torch.argmax(y[0]))
+        feat = acts['Mixed_5c']
+        feat.retain_grad()
+        y[0, target].backward()
+        out[f'{tag}_logits'] = logits.detach().numpy()
+        out[f'{tag}_probs'] = y.detach().numpy()
+        out[f'{tag}_target'] = np.array(target)
+        for n, a in acts.items():
+            out[f'{tag}_norm_{n}'] = np.array(float(a.detach().double().norm()))
+        f = feat.detach().numpy().ravel()
+        fi = sample_idx(f'g/i3d/{tag}/feat', f.size)
+        out[f'{tag}_feat_idx'] = fi
+        out[f'{tag}_feat_val'] = f[fi]
+        out[f'{tag}_feat_shape'] = np.array(feat.shape)
+        gf = feat.grad.numpy().ravel()
+        out[f'{tag}_dfeat_val'] = gf[fi]
+        dx = x.grad.numpy().ravel()
+        di = sample_idx(f'g/i3d/{tag}/dx', dx.size, 4096)
+        out[f'{tag}_dx_idx'] = di
+        out[f'{tag}_dx_val'] = dx[di]
+        out[f'{tag}_dx_norm'] = np.array(float(np.linalg.norm(dx.astype(np.float64))))
+        out[f'{tag}_dx_sum_per_frame'] = x.grad.numpy()[0].astype(np.float64).sum(axis=(0, 2, 3))
+    save('i3d', **out)
+
+
+# ---------------------------------------------------------------- CLSTM
+def gen_clstm():
+    out = {}
+    for C in (1, 3):
+        m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=C, conv_kernel_size=(5, 5),
+                          lstm_layers=2, step=32, image_size=(160, 120), conv_stride=2,
+                          effective_step=[7, 15, 23, 31], add_softmax=True).eval()
+        sd = R.clstm_state_dict(channels=C, tag=f'clstm{C}')
+        m.load_state_dict(R.to_torch(sd))
+        x = torch.from_numpy(R.clip(3, C, 32, 120, 160) / 255.0)[None].repeat(2, 1, 1, 1, 1)
+        x[1] = torch.from_numpy(R.clip(4, C, 32, 120, 160) / 255.0)
+        x.requires_grad_()
+        y = m(x)
+        m.add_softmax = False
+        with torch.no_grad():
+            logits = m(x)
+        (y[0, 2] + y[1, 4]).backward()
+        out[f'c{C}_probs'] = y.detach().numpy()
+        out[f'c{C}_logits'] = logits.numpy()
+        dx = x.grad.numpy().ravel()
+        di = sample_idx(f'g/clstm/{C}/dx', dx.size, 4096)
+        out[f'c{C}_dx_idx'] = di
+        out[f'c{C}_dx_val'] = dx[di]
+        out[f'c{C}_dx_norm'] = np.array(float(np.linalg.norm(dx.astype(np.float64))))
+        out[f'c{C}_dx_sum_per_frame'] = x.grad.numpy().astype(np.float64).sum(axis=(1, 3, 4))
+    save('clstm', **out)
+
+
+# ---------------------------------------------------------------- Grad-CAM
+def gen_gradcam():
+    out = {}
+    m = _i3d(False)
+    x = torch.from_numpy(R.clip(11))[None]
+    for per_frame in (True, False):
+        gc = ref_gc.GradCamVideo(model=m, target_layer_names=['Mixed_5c'], class_dict=None,
+                                 use_cuda=False, input_spatial_size=(224, 224),
+                                 normalizePerFrame=per_frame, archType="I3D")
+        cam, output = gc(x, None)
+        tag = 'pf' if per_frame else 'glob'
+        out[f'{tag}_output'] = output.detach().numpy()
+        out[f'{tag}_cam_small'] = cam[:, ::8, ::8]
+        out[f'{tag}_cam_sum'] = np.array(cam.astype(np.float64).sum())
+        out[f'{tag}_cam_rows'] = cam[[0, 7, 8, 15]][:, [0, 100, 223]]
+    gc = ref_gc.GradCamVideo(model=m, target_layer_names=['Mixed_5c'], class_dict=None,
+                             use_cuda=False, input_spatial_size=(224, 224),
+                             normalizePerFrame=True, archType="I3D")
+    cam, output = gc(x, 5)
+    out['idx5_cam_small'] = cam[:, ::8, ::8]
+    out['idx5_weights'] = np.mean(gc.extractor.get_gradients()[-1].numpy(), axis=(2, 3, 4))[0]
+    save('gradcam', **out)
+
+
+# ---------------------------------------------------------------- search
+def _ref_search(model, x, target, lam1, lam2, N, T):
+    """Harness around the reference's own mask.py + model following
+    FindMasksComparison_I3D_smth.py:188-235 (the published driver cannot run,
+    SURVEY.md F8).  init_mask is restated device-agnostically because
+    mask.py:131 hard-codes torch.cuda.FloatTensor."""
+    def score_fn(v):
+        return model(v)[0, target]
+    with torch.no_grad():
+        frozen = x[:, :, :1].expand_as(x).contiguous()
+        full = score_fn(frozen)
+        orig = score_fn(x)
+        cen, ratios = [], []
+        for i in range(1, T // 2):
+            nm = torch.ones(T)
+            nm[:i] = 0
+            nm[-i:] = 0
+            c = score_fn(ref_mask.perturb_sequence(x, nm, perturbation_type='freeze'))
+            r = (orig - c) / (orig - full)
+            cen.append(float(c))
+            ratios.append(float(r))
+            if r < 0.9:
+                break
+        tm = torch.where(nm == 0, torch.tensor(-5.0), torch.tensor(5.0))
+    init = tm.clone()
+    tm.requires_grad_()
+    opt = torch.optim.Adam([tm], lr=0.2)
+    traj = []
+    for n in range(N):
+        mc = torch.sigmoid(tm)
+        l1 = lam1 * torch.sum(torch.abs(mc))
+        tv = lam2 * ref_mask.calc_tv_norm(mc, p=3, q=3)
+        cl = model(ref_mask.perturb_sequence(x, mc, perturbation_type='freeze'))[0, target]
+        loss = l1 + tv + cl
+        opt.zero_grad()
+        loss.backward()
+        if n == 0:
+            g0 = tm.grad.numpy().copy()
+        opt.step()
+        traj.append([loss.item(), l1.item(), tv.item(), cl.item()])
+        print('  iter', n, traj[-1], flush=True)
+    final = torch.sigmoid(tm.detach())
+    with torch.no_grad():
+        rev = model(ref_mask.perturb_sequence(x, final, perturbation_type='reverse'))[0, target]
+    return dict(full=float(full), orig=float(orig), central=np.array(cen), ratios=np.array(ratios),
+                init=init.numpy(), traj=np.array(traj), mask=final.numpy(), grad0=g0,
+                freeze_score=traj[-1][3], reverse_score=float(rev))
+
+
+def gen_search():
+    out = {}
+    m = _i3d(False)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.from_numpy(R.clip(21))[None]
+    with torch.no_grad():
+        target = int(torch.argmax(m(x)[0]))
+    r = _ref_search(m, x, target, 0.01, 0.02, 12, 16)
+    out['s16_target'] = np.array(target)
+    for k, v in r.items():
+        out[f's16_{k}'] = np.asarray(v)
+    # CLSTM search, KTH lambdas (KTH:105-118)
+    c = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=1, conv_kernel_size=(5, 5),
+                      lstm_layers=2, step=32, image_size=(160, 120), conv_stride=2,
+                      effective_step=[7, 15, 23, 31], add_softmax=True).eval()
+    c.load_state_dict(R.to_torch(R.clstm_state_dict(channels=1, tag='clstm1')))
+    for p in c.parameters():
+        p.requires_grad_(False)
+    xc = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0)[None]
+    with torch.no_grad():
+        tc = int(torch.argmax(c(xc)[0]))
+    r = _ref_search(c, xc, tc, 0.02, 0.04, 30, 32)
+    out['c1_target'] = np.array(tc)
+    for k, v in r.items():
+        out[f'c1_{k}'] = np.asarray(v)
+    save('search', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search']
+    for w in which:
+        print('==', w, flush=True)
+        globals()['gen_' + w]()

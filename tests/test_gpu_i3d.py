@@ -1,0 +1,133 @@
+"""Whole-I3D parity on the GPU: HIP plan vs the reference model's outputs
+(tests/golden/i3d.npz, gradcam.npz, search.npz) at the BASELINE shapes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s16():
+    import ivf_engine
+    import ivf_recipe as R
+    eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=2, softmax=True)
+    eng.load_state_dict(R.i3d_state_dict(num_classes=174))
+    return eng
+
+
+@pytest.fixture(scope="module")
+def k32():
+    import ivf_engine
+    import ivf_recipe as R
+    eng = ivf_engine.I3DEngine(6, (3, 32, 120, 160), max_batch=1, head_hw=(4, 5), head_time_base=4,
+                               softmax=True)
+    eng.load_state_dict(R.i3d_state_dict(num_classes=6, tag='i3d_kth'))
+    return eng
+
+
+def _check_forward_backward(eng, tag, shape, g):
+    import ivf_recipe as R
+    x = torch.from_numpy(R.clip(7, *shape))[None].cuda()
+    probs, logits = eng.forward(x, want_logits=True)
+    assert rel_err(logits.cpu().numpy(), g[f'{tag}_logits']) < 1e-3        # north_star: 1e-3 relative fp32
+    assert rel_err(probs.cpu().numpy(), g[f'{tag}_probs']) < 1e-3
+    assert int(torch.argmax(probs[0])) == int(g[f'{tag}_target'])          # integer output: bit-exact
+    import ivf_arch as arch
+    for n in arch.ENDPOINTS:
+        a = eng.endpoint(n, 1)
+        ref = float(g[f'{tag}_norm_{n}'])
+        assert abs(float(a.double().norm()) - ref) < 1e-4 * ref, n
+    feat = eng.endpoint('Mixed_5c', 1).cpu().numpy().ravel()
+    assert list(eng.endpoint('Mixed_5c', 1).shape) == g[f'{tag}_feat_shape'].tolist()
+    assert rel_err(feat[g[f'{tag}_feat_idx']], g[f'{tag}_feat_val']) < 1e-3
+    score, dx = eng.backward(1, target=[int(g[f'{tag}_target'])])
+    assert abs(float(score) - float(g[f'{tag}_probs'][0, int(g[f'{tag}_target'])])) < 1e-5
+    dxn = dx.cpu().numpy()
+    assert rel_err(dxn.ravel()[g[f'{tag}_dx_idx']], g[f'{tag}_dx_val']) < 2e-3
+    assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-3 * float(g[f'{tag}_dx_norm'])
+    spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
+    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < 5e-3
+
+
+def test_i3d_s16_forward_backward(s16, golden):
+    _check_forward_backward(s16, 's16', (3, 16, 224, 224), golden('i3d'))
+
+
+def test_i3d_k32_forward_backward(k32, golden):
+    _check_forward_backward(k32, 'k32', (3, 32, 120, 160), golden('i3d'))
+
+
+def test_batch_rows_independent(s16):
+    """eval-mode BN => rows are independent: a clip's result must not
+    depend on its batch neighbours, bit for bit."""
+    import ivf_recipe as R
+    a = torch.from_numpy(R.clip(7))[None].cuda()
+    b = torch.from_numpy(R.clip(8))[None].cuda()
+    pa = s16.forward(a).clone()
+    pab = s16.forward(torch.cat([b, a]))
+    assert torch.equal(pab[1], pa[0])
+
+
+def test_gradcam_vs_reference(s16, golden):
+    import ivf_recipe as R
+    g = golden('gradcam')
+    x = torch.from_numpy(R.clip(11))[None].cuda()
+    for tag, pf in (('pf', True), ('glob', False)):
+        cam, probs = s16.gradcam(x, None, per_frame=pf)
+        cam = cam[0].cpu().numpy()
+        assert cam.shape == (16, 224, 224) and cam.dtype == np.float32
+        assert rel_err(probs.cpu().numpy(), g[f'{tag}_output']) < 1e-3
+        ref = g[f'{tag}_cam_small']
+        got = cam[:, ::8, ::8]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.max(np.abs(got[ok] - ref[ok])) < 2e-3          # maps are normalised to [0,1]
+        rows = cam[[0, 7, 8, 15]][:, [0, 100, 223]]
+        okr = ~np.isnan(g[f'{tag}_cam_rows'])
+        assert np.max(np.abs(rows[okr] - g[f'{tag}_cam_rows'][okr])) < 2e-3
+        # Grad-CAM L1 vs reference (BASELINE metric), on the sub-sampled map
+        l1 = float(np.mean(np.abs(got[ok] - ref[ok])))
+        assert l1 < 5e-4
+    cam5, _ = s16.gradcam(x, [5], per_frame=True)
+    got = cam5[0].cpu().numpy()[:, ::8, ::8]
+    ref = g['idx5_cam_small']
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(got[ok] - ref[ok])) < 2e-3
+
+
+def test_search_trajectory_vs_reference(s16, golden):
+    """12 iterations of the hot loop vs the reference's mask.py + model + torch Adam."""
+    import ivf_recipe as R
+    g = golden('search')
+    x = torch.from_numpy(R.clip(21))[None].cuda()
+    probs = s16.forward(x)
+    target = int(torch.argmax(probs[0]))
+    assert target == int(g['s16_target'])
+    assert abs(float(probs[0, target]) - float(g['s16_orig'])) < 1e-3 * float(g['s16_orig'])
+    # init_mask scores (mask.py:121-154)
+    T = 16
+    ones = torch.ones(1, T, device='cuda')
+    full = s16.perturbed_forward(x, ones, 'freeze')[0, target]
+    assert abs(float(full) - float(g['s16_full'])) < 1e-3 * float(g['s16_full'])
+    for i, ref in enumerate(g['s16_central'], start=1):
+        m = torch.ones(1, T, device='cuda')
+        m[0, :i] = 0
+        m[0, T - i:] = 0
+        c = s16.perturbed_forward(x, m, 'freeze')[0, target]
+        assert abs(float(c) - float(ref)) < 1e-3 * float(ref)
+    raw = torch.from_numpy(g['s16_init'])[None].cuda().contiguous()
+    traj, state = s16.search(x, [target], raw, 0.01, 0.02, 12)
+    traj = traj[:, 0].cpu().numpy()
+    ref = g['s16_traj']
+    assert np.max(np.abs(traj - ref) / np.abs(ref)) < 1e-2        # north_star: loss trajectory within 1e-2
+    assert np.max(np.abs(traj[:, 3] - ref[:, 3]) / ref[:, 3]) < 2e-3
+    final = torch.sigmoid(raw)[0].cpu().numpy()
+    assert np.max(np.abs(final - g['s16_mask'])) < 2e-3
+    # integer outputs bit-exact: snapped mask, ranking
+    assert np.array_equal(final > 0.5, g['s16_mask'] > 0.5)
+    rev = s16.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
+    assert abs(float(rev) - float(g['s16_reverse_score'])) < 2e-3 * float(g['s16_reverse_score'])

@@ -1,0 +1,153 @@
+"""HIP conv / pool kernels through the C-ABI vs the reference's own outputs
+(tests/golden/units.npz, produced by I3D_doubled.Unit3D / MaxPool3dSamePadding)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+UNIT_CASES = {  # name: (cin, cout, k, stride, in T,H,W) -- same table as make_golden.py
+    'k1': (24, 40, (1, 1, 1), (1, 1, 1), (3, 5, 6)),
+    'k3': (8, 12, (3, 3, 3), (1, 1, 1), (4, 7, 9)),
+    'k3_c16': (16, 48, (3, 3, 3), (1, 1, 1), (2, 7, 7)),
+    'k7s2_even': (3, 16, (7, 7, 7), (2, 2, 2), (8, 16, 18)),
+    'k7s2_odd': (3, 16, (7, 7, 7), (2, 2, 2), (7, 15, 17)),
+    'k7s1t': (3, 8, (7, 7, 7), (1, 2, 2), (6, 12, 12)),
+}
+POOL_CASES = {
+    'p133': ((1, 3, 3), (1, 2, 2), (3, 8, 10)),
+    'p133_odd': ((1, 3, 3), (1, 2, 2), (3, 7, 9)),
+    'p333s2': ((3, 3, 3), (2, 2, 2), (4, 8, 8)),
+    'p333s2_odd': ((3, 3, 3), (2, 2, 2), (5, 15, 7)),
+    'p222': ((2, 2, 2), (2, 2, 2), (4, 6, 8)),
+    'p222_odd': ((2, 2, 2), (2, 2, 2), (3, 7, 5)),
+    'p333s1': ((3, 3, 3), (1, 1, 1), (3, 5, 6)),
+    'p333s1t1': ((3, 3, 3), (1, 2, 2), (4, 8, 8)),
+}
+
+
+def to_cl(x, cpad=None):
+    """NCTHW -> channels-last [B,T,H,W,Cpad] on the GPU."""
+    B, C, T, H, W = x.shape
+    cpad = cpad or C
+    y = torch.zeros(B, T, H, W, cpad, device='cuda')
+    y[..., :C] = x.permute(0, 2, 3, 4, 1)
+    return y.contiguous()
+
+
+def from_cl(y, C):
+    return y[..., :C].permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("name", list(UNIT_CASES))
+def test_unit3d_fwd_bwd(name, golden):
+    import ivf_arch as arch
+    import ivf_lib as L
+    import ivf_recipe as R
+    lib = L.lib()
+    g = golden('units')
+    cin, cout, k, s, thw = UNIT_CASES[name]
+    cinp = (cin + 3) // 4 * 4
+    B = 2
+    dev = 'cuda'
+    w = torch.from_numpy(R.uniform(f'g/unit/{name}/w', (cout, cin) + k, -0.2, 0.2)).to(dev)
+    bn = [torch.from_numpy(R.uniform(f'g/unit/{name}/{t}', (cout,), lo, hi)).to(dev)
+          for t, lo, hi in (('g', 0.5, 1.5), ('b', -0.3, 0.3), ('m', -0.3, 0.3), ('v', 0.5, 1.5))]
+    x = torch.from_numpy(R.uniform(f'g/unit/{name}/x', (B, cin) + thw, -1, 1)).to(dev)
+    pads = [arch.same_pad(n, kk, ss)[0] for n, kk, ss in zip(thw, k, s)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    gy = torch.from_numpy(R.uniform(f'g/unit/{name}/gy', (B, cout) + tuple(outs), -1, 1)).to(dev)
+
+    scale = torch.empty(cout, device=dev)
+    shift = torch.empty(cout, device=dev)
+    L.check(lib.ivf_bn_fold(L.ptr(bn[0]), L.ptr(bn[1]), L.ptr(bn[2]), L.ptr(bn[3]), 1e-3, L.ptr(scale),
+                            L.ptr(shift), cout, L.stream()))
+    taps = k[0] * k[1] * k[2]
+    wf = torch.empty(cout * taps * cinp, device=dev)
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(w), L.ptr(wf), cout, cin, cinp, *k, L.stream()))
+    xcl = to_cl(x, cinp)
+    ycl = torch.full((B,) + tuple(outs) + (cout,), float('nan'), device=dev)
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cinp, cinp, 0
+    d.To, d.Ho, d.Wo = outs
+    d.Cout, d.out_ld, d.out_coff = cout, cout, 0
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = s
+    d.pT, d.pH, d.pW = pads
+    d.relu = 1
+    L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), L.ptr(scale), L.ptr(shift), None,
+                           L.ptr(ycl), L.stream()))
+    y = from_cl(ycl, cout).cpu().numpy()
+    assert rel_err(y, g[f'unit_{name}_y']) < 1e-5
+
+    # backward-data: gradient gated by the unit's own ReLU, BN scale folded in the pack
+    gate = (ycl > 0).float()
+    gcl = (to_cl(gy) * gate).contiguous()
+    n_el = lib.ivf_conv3d_pack_bwd_elems(cout, cinp, *k, *s, *pads)
+    wb = torch.empty(n_el, device=dev)
+    geom = L.BwdGeom()
+    L.check(lib.ivf_conv3d_pack_bwd(L.ptr(w), L.ptr(scale), L.ptr(wb), cout, cin, cinp, *k, *s, *pads,
+                                    ctypes.byref(geom), L.stream()))
+    dxcl = torch.full((B,) + thw + (cinp,), float('nan'), device=dev)
+    e = L.ConvDesc()
+    e.B, e.Ti, e.Hi, e.Wi = B, *outs
+    e.Cin, e.in_ld, e.in_coff = cout, cout, 0
+    e.kT, e.kH, e.kW = geom.kT, geom.kH, geom.kW
+    e.sT = e.sH = e.sW = 1
+    e.pT, e.pH, e.pW = geom.pT, geom.pH, geom.pW
+    e.out_ld, e.out_coff = cinp, 0
+    if geom.d2s:
+        e.d2s = 1
+        e.bsT, e.bsH, e.bsW = s
+        e.To, e.Ho, e.Wo = [-(-n // ss) for n, ss in zip(thw, s)]
+        e.Cout = geom.rows
+        e.dT, e.dH, e.dW = thw
+        e.dC = cinp
+    else:
+        e.To, e.Ho, e.Wo = thw
+        e.Cout = cinp
+    L.check(lib.ivf_conv3d(ctypes.byref(e), L.ptr(gcl), L.ptr(wb), None, None, None, L.ptr(dxcl), L.stream()))
+    dx = from_cl(dxcl, cin).cpu().numpy()
+    assert np.isfinite(dxcl.cpu().numpy()).all()
+    assert rel_err(dx, g[f'unit_{name}_dx']) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(POOL_CASES))
+def test_maxpool_fwd_bwd(name, golden):
+    import ivf_arch as arch
+    import ivf_lib as L
+    import ivf_recipe as R
+    lib = L.lib()
+    g = golden('units')
+    k, s, thw = POOL_CASES[name]
+    B, C = 2, 6
+    xv = np.maximum(R.uniform(f'g/pool/{name}/x', (B, C) + thw, -1, 1), 0)
+    x = torch.from_numpy(xv).cuda()
+    pads = [arch.same_pad(n, kk, ss)[0] for n, kk, ss in zip(thw, k, s)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    gy = torch.from_numpy(R.uniform(f'g/pool/{name}/gy', (B, C) + tuple(outs), -1, 1)).cuda()
+    cp = 8
+    xcl = to_cl(x, cp)
+    ycl = torch.zeros((B,) + tuple(outs) + (cp,), device='cuda')
+    idx = torch.zeros((B,) + tuple(outs) + (cp,), dtype=torch.uint8, device='cuda')
+    d = L.PoolDesc()
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, *thw, cp, cp, 0
+    d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *outs, cp, 0
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = s
+    d.pT, d.pH, d.pW = pads
+    L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(ycl), L.ptr(idx), L.stream()))
+    assert np.array_equal(from_cl(ycl, C).cpu().numpy(), g[f'pool_{name}_y'])   # bit-exact
+    dxcl = torch.full_like(xcl, float('nan'))
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy, cp)), L.ptr(idx), L.ptr(dxcl), None, 0,
+                                  L.stream()))
+    dx = from_cl(dxcl, C).cpu().numpy()
+    ref = g[f'pool_{name}_dx']
+    # same winners (ties incl. zero padding) -> identical routing; sums of <= 27 terms
+    assert np.array_equal(dx != 0, ref != 0)
+    assert np.allclose(dx, ref, rtol=1e-6, atol=1e-7)
