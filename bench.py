@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of the FULL perturbation-mask search on I3D.
+
+A "step" = one pass of the hot path over one batch of synthetic clips per GPU:
+baseline forward -> init_mask('central') -> 300 Adam iterations (freeze scan,
+I3D forward, backward-data, reverse scan, TV/L1, Adam) -> reverse score ->
+Grad-CAM, for `--batch` 16-frame 224x224 clips (BASELINE.json configs[1];
+reference loop: FindMasksComparison_I3D_smth.py:166-277).  Clips are resident in
+HBM before the timed region.  N>1: one process per GPU (torchrun), clips sharded
+clip_id % world, no data-path collective; one RCCL all_gather of the fixed-size
+per-clip records inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+VARIANT_NAMES = ("conv3d_igemm_kernel<128,128,2,2>", "conv3d_igemm_kernel<128,64,4,1>",
+                 "conv3d_igemm_kernel<128,32,4,1>")
+
+
+def cpu_baseline(n_iter_total, sample_iters, lam1, lam2, threads):
+    """The CPU oracle (torch fp32 restatement of the reference path, oracle/) on the
+    host cores of this box: one clip, init_mask + `sample_iters` iterations + reverse
+    score + Grad-CAM; the iteration cost is extrapolated linearly to n_iter_total."""
+    import ivf_recipe as R
+    from oracle import gradcam_ref, i3d_ref, mask_ref
+    torch.set_num_threads(threads)
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(1000))[None]
+    with torch.no_grad():
+        out = i3d_ref.forward(x, sd)
+    target = int(out[0].argmax())
+
+    def score_fn(v):
+        return i3d_ref.forward(v, sd)[0, target]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        i3d_ref.forward(x, sd)
+        tm, _ = mask_ref.init_mask_central(x, score_fn, 0.9, 'freeze')
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = mask_ref.search_clip(x, score_fn, lam1, lam2, sample_iters, init=tm)   # includes reverse score
+    t_loop = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        score_fn(mask_ref.perturb_sequence(x, res['mask'], 'reverse'))
+    t_rev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gradcam_ref.gradcam_i3d(x, sd, None)
+    t_gc = time.perf_counter() - t0
+    per_iter = (t_loop - t_rev) / sample_iters
+    total = t_init + per_iter * n_iter_total + t_rev + t_gc
+    return dict(value=1.0 / total, unit="clips/s", cores=threads, kind="port",
+                sample=(f"1 clip [1,3,16,224,224]: init_mask {t_init:.1f}s + {sample_iters} of {n_iter_total} "
+                        f"iterations ({per_iter:.2f}s each, extrapolated linearly) + reverse {t_rev:.1f}s + "
+                        f"Grad-CAM {t_gc:.1f}s"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (reference batch_size=16)")
+    ap.add_argument("--iters", type=int, default=300, help="Adam iterations per search (reference N=300)")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+
+    import ivf_engine
+    import ivf_lib as L
+    import ivf_recipe as R
+    import ivf_search
+
+    lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
+    T, B = args.frames, args.batch
+    eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=B, softmax=True,
+                               stride_mod_layers="" if T == 16 else "none", device=dev)
+    eng.load_state_dict(R.i3d_state_dict(num_classes=174))
+    searcher = ivf_search.MaskSearch(eng, lam1, lam2, args.iters, "freeze", grad_cam_type="guessed",
+                                     do_gradcam=True)
+    # synthetic clips, resident in HBM before the timed region; shard: clip_id % world == rank
+    n_steps_total = args.warmup + args.steps
+    clip_ids = [[(s * B + i) * world + rank for i in range(B)] for s in range(n_steps_total)]
+    uniq = sorted({c % 64 for ids in clip_ids for c in ids})      # 64 distinct synthetic clips, reused
+    bank = {c: torch.from_numpy(R.clip(c, 3, T, 224, 224)).to(dev) for c in uniq}
+    batches = [torch.stack([bank[c % 64] for c in ids]) for ids in clip_ids]
+    labels = [[R.label(c, 174) for c in ids] for ids in clip_ids]
+
+    def step(i):
+        res = searcher.run(batches[i], labels[i])
+        rec = ivf_search.pack_records(clip_ids[i], res, T)
+        if world > 1:
+            gathered = torch.empty(world * rec.shape[0], rec.shape[1], device=dev)
+            dist.all_gather_into_tensor(gathered, rec)
+            return gathered, res
+        return rec, res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    # sample conv launches on every 16th iteration with HIP events on the launch stream
+    sample_every = 16
+    L.check(L.lib().ivf_profile_enable(sample_every, 200000))
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.warmup, n_steps_total):
+        last = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = (ctypes.c_double * 3)()
+    launches = (ctypes.c_longlong * 3)()
+    flops = (ctypes.c_double * 3)()
+    L.check(L.lib().ivf_profile_collect(ms, launches, flops))
+    L.check(L.lib().ivf_profile_disable())
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        dom = int(np.argmax([ms[v] for v in range(3)]))
+        roofline = None
+        if launches[dom] > 0:
+            avg_ms = ms[dom] / launches[dom]
+            achieved = (flops[dom] / launches[dom]) / (avg_ms * 1e-3) / 1e12
+            tot_ms = sum(ms[v] for v in range(3))
+            tot_fl = sum(flops[v] for v in range(3))
+            roofline = {
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": VARIANT_NAMES[dom], "avg_launch_ms": round(avg_ms, 4),
+                "sampled_launches": int(launches[dom]),
+                "algorithmic_gflop_per_launch": round(flops[dom] / launches[dom] / 1e9, 3),
+                "all_conv_variants": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                      "share_of_sampled_conv_time": {VARIANT_NAMES[v]: round(ms[v] / tot_ms, 3)
+                                                                     for v in range(3)}},
+                "peak_dtype": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+            }
+        out = {
+            "metric": "clips/sec full mask-search (I3D, 16f, 300 iters)",
+            "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"I3D perturbation mask search, {args.iters} iters, synthetic clips "
+                                   f"[{B},3,{T},224,224] per GPU per step (BASELINE configs[1]); init_mask + "
+                                   f"search + reverse score + Grad-CAM",
+                       "clips_per_gpu_per_step": B, "iters": args.iters, "frames": T,
+                       "lam1": lam1, "lam2": lam2, "sharding": f"clip_id % {world}, all_gather of records"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                pass
+            out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample_iters, lam1, lam2, threads)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

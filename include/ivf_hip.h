@@ -261,6 +261,20 @@ int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int* target, in
 /* argmax over K of probs [b,K] -> target [b] (np.argmax, grad_cam_videos.py:69-70). */
 int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream);
 
+/* Algorithmic forward FLOPs of all Unit3D convolutions for one clip (2*MAC, real
+ * channel counts; backward-data costs the same again).  SURVEY.md section 8d. */
+double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net);
+
+/* ------------------------------------------------------------------ measurement */
+
+/* HIP-event timing of the implicit-GEMM convolution launches on their own stream,
+ * sampled on every `every`-th iteration of ivf_*_search (bench.py's roofline leg).
+ * collect: per tile variant v (0: 128x128, 1: 128x64, 2: 128x32) summed kernel
+ * milliseconds, launch count and algorithmic FLOPs of the sampled launches. */
+int ivf_profile_enable(int every, int max_launches);
+int ivf_profile_disable(void);
+int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);
+
 #ifdef __cplusplus
 }
 #endif

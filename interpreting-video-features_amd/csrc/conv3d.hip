@@ -330,7 +330,9 @@ static int launch_variant(ConvKArgs& a, hipStream_t s) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
+  const bool timed = prof_begin(s, BN == 128 ? 0 : (BN == 64 ? 1 : 2));
   hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }

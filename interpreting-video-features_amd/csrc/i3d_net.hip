@@ -44,6 +44,7 @@ struct Op {
   int conv = -1;
   int k[3], s[3], p[3];
   size_t idx_off = 0;  // pool arg-max bytes offset (in bytes, inside workspace)
+  double flops_per_clip = 0.0;  // algorithmic: 2 * out positions * Cout * taps * REAL Cin (same for bwd-data)
   // backward bookkeeping for grad(src)
   bool bwd_accumulate = false, bwd_mask = false;
 };
@@ -113,6 +114,10 @@ struct Builder {
       int f, bk;
       same_pad(dims[d], c.k[d], c.s[d], &f, &bk);
       o.p[d] = f; c.pad[d] = f;
+    }
+    {
+      const ActBuf& t = n->bufs[dst];
+      o.flops_per_clip = 2.0 * t.T * t.H * t.W * c.cout * c.k[0] * c.k[1] * c.k[2] * c.cin;
     }
     n->ops.push_back(o);
     n->bufs[src].consumers++;
@@ -322,6 +327,7 @@ static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_fwd(n, o, b, &d);
+      prof_set_flops(o.flops_per_clip * b);
       IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off,
                                n->warena + L.shift_off, nullptr, n->act(o.dst), s));
     } else {
@@ -358,6 +364,7 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_bwd(n, o, b, &d);
+      prof_set_flops(o.flops_per_clip * b);
       IVF_PROPAGATE(ivf_conv3d(&d, n->grad(o.dst), n->warena + L.wb_off, nullptr, nullptr, gate,
                                n->grad(o.src), s));
     } else {
@@ -560,10 +567,16 @@ extern "C" int ivf_i3d_backward(ivf_i3d_t* net, int b, const int* target, const 
 extern "C" int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** ptr, int* T, int* H, int* W,
                                 int* C, int* ld) {
   IVF_CHECK_ARG(net && name && net->ws, "i3d_endpoint: bad args / not bound");
+  std::string want(name);
+  bool want_grad = false;
+  if (want.size() > 5 && want.compare(want.size() - 5, 5, ":grad") == 0) {
+    want_grad = true;   // gradient buffer of the last backward (ReLU-gated where the endpoint is a ReLU output)
+    want.resize(want.size() - 5);
+  }
   for (size_t i = 0; i < net->bufs.size(); ++i) {
     const ActBuf& b = net->bufs[i];
-    if (b.name == name) {
-      if (ptr) *ptr = net->act((int)i);
+    if (b.name == want) {
+      if (ptr) *ptr = want_grad ? net->grad((int)i) : net->act((int)i);
       if (T) *T = b.T;
       if (H) *H = b.H;
       if (W) *W = b.W;
@@ -592,6 +605,7 @@ extern "C" int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* 
   float* dsig = net->at<float>(net->off_dsig);
   float* score = net->at<float>(net->off_score);
   for (int it = 0; it < N; ++it) {
+    prof_set_iteration(it);
     IVF_PROPAGATE(ivf_mask_reg(raw_mask, b, T, lam1, lam2, sig, terms, dreg, s));              // smth:198-200
     IVF_PROPAGATE(ivf_freeze_fwd(x, sig, net->act(0), b, c.C, T, HW, 1, 4, s));                // smth:202
     IVF_PROPAGATE(run_forward(net, b, nullptr, nullptr, s));                                    // smth:202-205
@@ -602,6 +616,7 @@ extern "C" int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* 
                                   traj ? traj + (size_t)it * b * 4 : nullptr, b, T, first_step + it, lr,
                                   beta1, beta2, eps, s));                                       // smth:207-214
   }
+  prof_set_iteration(-1);   // sampling off outside the loop
   return IVF_OK;
 }
 
@@ -648,4 +663,11 @@ extern "C" int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int*
   IVF_CHECK_ARG(c.T / f.T >= 1, "i3d_gradcam: clip shorter than the feature map");
   return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, f.T, f.H, f.W, out_h, out_w,
                                   c.T / f.T, per_frame, s);
+}
+
+extern "C" double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net) {
+  double f = 0.0;
+  if (net)
+    for (const Op& o : net->ops) f += o.flops_per_clip;
+  return f;
 }

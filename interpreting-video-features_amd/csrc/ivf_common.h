@@ -11,6 +11,12 @@ namespace ivf {
 
 void set_error(const char* fmt, ...);
 
+// launch profiler (ivf_common.hip)
+void prof_set_iteration(int it);
+void prof_set_flops(double algorithmic_flops);
+bool prof_begin(hipStream_t s, int variant);
+void prof_end(hipStream_t s);
+
 #define IVF_CHECK_ARG(cond, ...)                 \
   do {                                           \
     if (!(cond)) {                               \

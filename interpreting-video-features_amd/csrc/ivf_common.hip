@@ -15,3 +15,79 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* ivf_last_error(void) { return ivf::g_err; }
 extern "C" int ivf_version(void) { return 100; }
+
+// ---------------------------------------------------------------- launch profiler
+// Optional HIP-event timing of the implicit-GEMM convolution launches, per tile
+// variant, on the stream they are launched on.  Sampled every `every`-th search
+// iteration so the event records do not perturb the timed region.
+#include <vector>
+namespace ivf {
+struct Prof {
+  bool enabled = false, active = false;
+  int every = 1;
+  size_t cap = 0, used = 0;
+  std::vector<hipEvent_t> ev;          // 2 per sampled launch
+  std::vector<int> variant;
+  std::vector<double> flops;
+  double next_flops = 0.0;
+};
+static Prof g_prof;
+void prof_set_iteration(int it) { g_prof.active = g_prof.enabled && it >= 0 && (it % g_prof.every == 0); }
+void prof_set_flops(double f) { g_prof.next_flops = f; }
+bool prof_begin(hipStream_t s, int variant) {
+  Prof& p = g_prof;
+  if (!p.active || p.used >= p.cap) return false;
+  if (p.ev.size() < 2 * (p.used + 1)) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+    p.ev.push_back(a);
+    p.ev.push_back(b);
+  }
+  p.variant.resize(p.used + 1);
+  p.flops.resize(p.used + 1);
+  p.variant[p.used] = variant;
+  p.flops[p.used] = p.next_flops;
+  (void)hipEventRecord(p.ev[2 * p.used], s);
+  return true;
+}
+void prof_end(hipStream_t s) {
+  Prof& p = g_prof;
+  (void)hipEventRecord(p.ev[2 * p.used + 1], s);
+  p.used++;
+}
+}  // namespace ivf
+
+extern "C" int ivf_profile_enable(int every, int max_launches) {
+  IVF_CHECK_ARG(every >= 1 && max_launches > 0, "profile_enable: bad args");
+  ivf::g_prof.enabled = true;
+  ivf::g_prof.active = false;
+  ivf::g_prof.every = every;
+  ivf::g_prof.cap = (size_t)max_launches;
+  ivf::g_prof.used = 0;
+  return IVF_OK;
+}
+
+extern "C" int ivf_profile_disable(void) {
+  ivf::g_prof.enabled = false;
+  ivf::g_prof.active = false;
+  return IVF_OK;
+}
+
+// Sums per tile variant v in [0,3): kernel_ms[v], launches[v], flops[v]; resets the sample.
+// Synchronises on the recorded events (call outside the timed region).
+extern "C" int ivf_profile_collect(double* kernel_ms, long long* launches, double* flops) {
+  IVF_CHECK_ARG(kernel_ms && launches && flops, "profile_collect: null pointer");
+  ivf::Prof& p = ivf::g_prof;
+  for (int v = 0; v < 3; ++v) { kernel_ms[v] = 0.0; launches[v] = 0; flops[v] = 0.0; }
+  for (size_t i = 0; i < p.used; ++i) {
+    IVF_CHECK_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
+    float ms = 0.f;
+    IVF_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    int v = p.variant[i];
+    kernel_ms[v] += ms;
+    launches[v] += 1;
+    flops[v] += p.flops[i];
+  }
+  p.used = 0;
+  return IVF_OK;
+}

@@ -58,8 +58,8 @@ class I3DEngine:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            L.lib().ivf_i3d_destroy(h)
+        if h is not None and h.value and L is not None and getattr(L, "_lib", None) is not None:
+            L._lib.ivf_i3d_destroy(h)
             self._h = c_void_p()
 
     @property

@@ -93,6 +93,11 @@ _SIGS = {
     "ivf_i3d_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "ivf_i3d_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
     "ivf_i3d_gradcam": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
+    "ivf_i3d_conv_flops_per_clip": (ctypes.c_double, [_P]),
+    "ivf_profile_enable": (c_int, [_I, _I]),
+    "ivf_profile_disable": (c_int, []),
+    "ivf_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),
+                                    POINTER(ctypes.c_double)]),
 }
 
 # entry points added by later translation units; bound when present in _SIGS_OPT

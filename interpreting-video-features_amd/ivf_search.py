@@ -1,0 +1,143 @@
+"""Batched per-clip mask search on top of a network engine (I3D or CLSTM_4).
+
+One call runs, for b DIFFERENT clips with b DIFFERENT masks, what the reference
+runs for one `batch_index` at a time (FindMasksComparison_I3D_smth.py:166-277):
+baseline scores -> init_mask('central') -> N Adam iterations -> reverse score ->
+Grad-CAM.  In eval mode the rows of a batch are independent, so
+per clip the numbers are the ones the reference computes.
+
+Everything that computes is a libivf_hip call; this file only sequences them
+and makes the handful of host decisions the reference makes on the host
+(which central mask to keep, mask.py:134-147).
+"""
+import numpy as np
+import torch
+
+import ivf_lib as L
+
+
+def central_masks(T, device):
+    """mask.py:135-137 for i = 1 .. T//2-1: ones with i zeros at each end."""
+    rows = []
+    for i in range(1, T // 2):
+        m = torch.ones(T)
+        m[:i] = 0
+        m[T - i:] = 0
+        rows.append(m)
+    return torch.stack(rows).to(device)
+
+
+def init_masks_central(engine, x, target, orig_score, threshold=0.9, mask_type="freeze"):
+    """mask.init_mask(mode='central'), mask.py:121-154, for b clips at once.
+    Returns (raw masks [b,T] in {-5,+5}, info dict).  The reference stops at the
+    first i whose score ratio drops below `threshold`; here all T//2-1 candidates are
+    scored (<= 6 extra forwards per clip) and the same i is selected afterwards, so
+    the loop needs one host sync instead of one per candidate."""
+    b, _, T = x.shape[0], x.shape[1], x.shape[2]
+    dev = x.device
+    idx = torch.arange(b, device=dev)
+    tl = target.long()
+    full = engine.perturbed_forward(x, torch.ones(b, T, device=dev), mask_type)[idx, tl]   # :123-128
+    cands = central_masks(T, dev)
+    cen = torch.stack([engine.perturbed_forward(x, cands[i][None].expand(b, T).contiguous(), mask_type)[idx, tl]
+                       for i in range(cands.shape[0])], dim=1)                                # :139-141
+    ratio = (orig_score[:, None] - cen) / (orig_score[:, None] - full[:, None])               # :142
+    below = ratio < threshold                      # NaN compares False, as in the reference (:143)
+    first = torch.where(below.any(dim=1), below.float().argmax(dim=1),
+                        torch.full((b,), cands.shape[0] - 1, device=dev))
+    chosen = cands[first]                                                                     # :147
+    raw = torch.where(chosen == 0, torch.tensor(-5.0, device=dev), torch.tensor(5.0, device=dev))  # :149-154
+    return raw.contiguous(), dict(full=full, central=cen, ratio=ratio, chosen_i=first + 1)
+
+
+def find_submasks_host(mask_row, thresh=0.1):
+    """Host view of the integer output of ivf_submask_pairs for one mask."""
+    T = mask_row.numel()
+    m = L.f32c(mask_row.detach().reshape(-1))
+    L.require_gpu(m)
+    run = torch.empty(T, dtype=torch.int32, device=m.device)
+    partner = torch.empty(T, dtype=torch.int32, device=m.device)
+    weight = torch.empty(T, device=m.device)
+    with torch.cuda.device(m.device):
+        L.check(L.lib().ivf_submask_pairs(L.ptr(m), T, float(thresh), L.ptr(run), L.ptr(partner), L.ptr(weight),
+                                          L.stream()))
+    runs = {}
+    for t, r in enumerate(run.cpu().tolist()):
+        if r >= 0:
+            runs.setdefault(r, []).append(t)
+    return [runs[r] for r in sorted(runs)]
+
+
+def frame_ranking(mask):
+    """Integer frame-importance ranking: stable argsort of -mask."""
+    return torch.argsort(-mask, dim=-1, stable=True)
+
+
+class MaskSearch:
+    def __init__(self, engine, lam1=0.01, lam2=0.02, n_iter=300, mask_type="freeze", threshold=0.9,
+                 lr=0.2, grad_cam_type="guessed", do_gradcam=True, run_temp_mask=True,
+                 normalize_per_frame=True, gradcam_size=None):
+        self.engine = engine
+        self.lam1, self.lam2, self.n_iter = float(lam1), float(lam2), int(n_iter)
+        self.mask_type, self.threshold, self.lr = mask_type, threshold, lr
+        self.grad_cam_type = grad_cam_type
+        self.do_gradcam, self.run_temp_mask = do_gradcam, run_temp_mask
+        self.normalize_per_frame = normalize_per_frame
+        self.gradcam_size = gradcam_size
+
+    def run(self, x, labels, want_traj=False):
+        """x [b,C,T,H,W] float32 on the GPU, labels [b] ints.  Returns a dict of device
+        tensors, one row per clip (nothing is copied to the host here)."""
+        eng = self.engine
+        b = x.shape[0]
+        dev = x.device
+        labels = torch.as_tensor(labels, device=dev).to(torch.int32).reshape(-1)
+        out = {}
+        probs = eng.forward(x)                                               # smth:176
+        pred = eng.argmax(probs)                                             # smth:181 / :217
+        target = pred if self.grad_cam_type == "guessed" else labels         # smth:179-184
+        idx = torch.arange(b, device=dev)
+        out["pred_class"] = pred
+        out["target"] = target
+        out["original_score_guess"] = probs[idx, pred.long()]
+        out["original_score_true"] = probs[idx, labels.long()]
+        if self.run_temp_mask:
+            raw, info = init_masks_central(eng, x, target, probs[idx, target.long()], self.threshold,
+                                           self.mask_type)                   # smth:188-190
+            out["init_mask"] = raw.clone()
+            traj, _ = eng.search(x, target, raw, self.lam1, self.lam2, self.n_iter, lr=self.lr,
+                                 want_traj=True)                             # smth:191-214
+            mask = torch.sigmoid(raw)                                        # smth:216
+            out["time_mask"] = mask
+            out["freeze_score"] = traj[-1, :, 3] if self.n_iter > 0 else torch.full((b,), float("nan"), device=dev)
+            rev = eng.perturbed_forward(x, mask, "reverse")                  # smth:234-235
+            out["reverse_score"] = rev[idx, target.long()]
+            out["ranking"] = frame_ranking(mask)
+            out["snapped"] = mask > 0.5                                      # mask.py:5-10
+            if want_traj:
+                out["traj"] = traj
+        if self.do_gradcam:
+            gc_target = pred if self.grad_cam_type == "guessed" else target  # smth:253,266-267
+            cam, _ = eng.gradcam(x, gc_target, per_frame=self.normalize_per_frame, out_hw=self.gradcam_size)
+            out["gradcam"] = cam                                             # smth:269
+        return out
+
+
+RECORD_FIELDS = ("clip_id", "pred_class", "target", "original_score_guess", "original_score_true",
+                 "freeze_score", "reverse_score")
+
+
+def pack_records(clip_ids, res, T):
+    """Fixed-size per-clip record [b, 7+T] float32 for the all-gather."""
+    cols = [torch.as_tensor(clip_ids, device=res["pred_class"].device).float()]
+    cols += [res[k].float() for k in RECORD_FIELDS[1:]]
+    rec = torch.stack(cols, dim=1)
+    return torch.cat([rec, res["time_mask"].float()], dim=1).contiguous()
+
+
+def unpack_record(row, T):
+    d = {k: row[i].item() for i, k in enumerate(RECORD_FIELDS)}
+    for k in ("clip_id", "pred_class", "target"):
+        d[k] = int(d[k])
+    d["time_mask"] = row[len(RECORD_FIELDS):len(RECORD_FIELDS) + T].cpu().numpy()
+    return d

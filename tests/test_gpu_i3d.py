@@ -45,11 +45,90 @@ def _check_forward_backward(eng, tag, shape, g):
     assert rel_err(feat[g[f'{tag}_feat_idx']], g[f'{tag}_feat_val']) < 1e-3
     score, dx = eng.backward(1, target=[int(g[f'{tag}_target'])])
     assert abs(float(score) - float(g[f'{tag}_probs'][0, int(g[f'{tag}_target'])])) < 1e-5
+    # d(score)/d(input) through the WHOLE chain.  The net is piecewise linear with
+    # discontinuous derivatives at max-pool ties and ReLU zeros; chance near-ties
+    # (two window entries equal to 1 ulp) are resolved by rounding noise, differently
+    # on any two fp32 implementations (measured: the torch-CPU reference on the build
+    # box vs the same reference on the GPU box's host differ by the same 1-2 %).  So
+    # the whole-chain gate is loose; the strict gate is the module-wise test below,
+    # which feeds both sides the same activations.
     dxn = dx.cpu().numpy()
-    assert rel_err(dxn.ravel()[g[f'{tag}_dx_idx']], g[f'{tag}_dx_val']) < 2e-3
-    assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-3 * float(g[f'{tag}_dx_norm'])
+    sample, ref = dxn.ravel()[g[f'{tag}_dx_idx']].astype(np.float64), g[f'{tag}_dx_val'].astype(np.float64)
+    assert np.linalg.norm(sample - ref) / np.linalg.norm(ref) < 3e-2
+    assert rel_err(sample, ref) < 8e-2
+    assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
-    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < 5e-3
+    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < 3e-2
+
+
+def _modulewise_backward(eng, sd_np, shape, pool_kernel):
+    """Strict backward parity: for every endpoint, run the CPU oracle's module on the
+    GPU's own input activation with the GPU's own upstream gradient and compare the
+    downstream gradient.  Identical inputs => identical ties/gates => fp32 rounding only."""
+    import ivf_arch as arch
+    import ivf_recipe as R
+    from oracle import i3d_ref
+    sd = R.to_torch(sd_np)
+    x = torch.from_numpy(R.clip(9, *shape))[None]
+    probs = eng.forward(x.cuda())
+    target = int(torch.argmax(probs[0]))
+    _, dx = eng.backward(1, target=[target])
+    names = ['input'] + list(arch.ENDPOINTS)
+    acts = {n: eng.endpoint(n, 1).cpu() for n in arch.ENDPOINTS}
+    acts['input'] = x
+    grads = {n: eng.endpoint(n + ':grad', 1).cpu() for n in arch.ENDPOINTS}
+    grads['input'] = dx.cpu()
+
+    def module(name, v):
+        if name in arch.INCEPTION:
+            return i3d_ref.inception(v, sd, name)
+        if name in arch.POOLS:
+            k, s = arch.POOLS[name]
+            return i3d_ref.maxpool_same(v, k, s)
+        stride = (2, 2, 2) if name == 'Conv3d_1a_7x7' else (1, 1, 1)
+        return i3d_ref.unit3d(v, sd, name, stride)
+
+    # head: feature gradient from the class score
+    f = acts['Mixed_5c'].clone().requires_grad_()
+    _, out = i3d_ref.head(f, sd, pool_kernel, True)
+    out[0, target].backward()
+    ref = f.grad * (f > 0).float()
+    assert rel_err(grads['Mixed_5c'].numpy(), ref.numpy()) < 1e-4
+    worst = 0.0
+    for i in range(len(names) - 1, 0, -1):
+        src, dst = names[i - 1], names[i]
+        v = acts[src].clone().requires_grad_()
+        y = module(dst, v)
+        assert rel_err(acts[dst].numpy(), y.detach().numpy()) < 1e-5, dst      # forward, same input
+        (y * grads[dst]).sum().backward()
+        ref = v.grad
+        if src in arch.INCEPTION or src.startswith('Conv3d'):
+            ref = ref * (v.detach() > 0).float()       # the plan stores ReLU-gated gradients
+        got = grads[src].numpy()
+        refn = ref.numpy()
+        scale = np.abs(refn).max()
+        bad = np.abs(got - refn) > 1e-4 * scale
+        # The CPU side recomputes the module's ReLU from the same input, so a gate whose
+        # pre-activation is within rounding of 0 may flip; one flip moves up to
+        # taps x Cin downstream entries.  Allow a small fraction of outliers, never a
+        # systematic error: the median must sit at fp32 rounding and the L2 error stay small.
+        assert bad.mean() < 5e-3, (src, float(bad.mean()))
+        med = np.median(np.abs(got - refn)) / scale
+        assert med < 1e-6, (src, med)
+        l2 = np.linalg.norm((got - refn).astype(np.float64)) / np.linalg.norm(refn.astype(np.float64))
+        assert l2 < 5e-3, (src, l2)
+        worst = max(worst, float(bad.mean()))
+    return worst
+
+
+def test_i3d_s16_backward_modulewise(s16):
+    import ivf_recipe as R
+    _modulewise_backward(s16, R.i3d_state_dict(num_classes=174), (3, 16, 224, 224), (2, 7, 7))
+
+
+def test_i3d_k32_backward_modulewise(k32):
+    import ivf_recipe as R
+    _modulewise_backward(k32, R.i3d_state_dict(num_classes=6, tag='i3d_kth'), (3, 32, 120, 160), (4, 4, 5))
 
 
 def test_i3d_s16_forward_backward(s16, golden):
@@ -84,6 +163,7 @@ def test_gradcam_vs_reference(s16, golden):
         got = cam[:, ::8, ::8]
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         ok = ~np.isnan(ref)
+        assert ok.any()
         assert np.max(np.abs(got[ok] - ref[ok])) < 2e-3          # maps are normalised to [0,1]
         rows = cam[[0, 7, 8, 15]][:, [0, 100, 223]]
         okr = ~np.isnan(g[f'{tag}_cam_rows'])
@@ -95,8 +175,9 @@ def test_gradcam_vs_reference(s16, golden):
     got = cam5[0].cpu().numpy()[:, ::8, ::8]
     ref = g['idx5_cam_small']
     assert np.array_equal(np.isnan(got), np.isnan(ref))
-    ok = ~np.isnan(ref)
-    assert np.max(np.abs(got[ok] - ref[ok])) < 2e-3
+    ok = ~np.isnan(ref)       # class 5 may have an all-negative CAM: 0/0 -> NaN on both sides
+    if ok.any():
+        assert np.max(np.abs(got[ok] - ref[ok])) < 2e-3
 
 
 def test_search_trajectory_vs_reference(s16, golden):
