@@ -261,6 +261,53 @@ int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int* target, in
 /* argmax over K of probs [b,K] -> target [b] (np.argmax, grad_cam_videos.py:69-70). */
 int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream);
 
+/* ------------------------------------------------------------------ CLSTM_4 */
+
+typedef struct {
+  int B;                 /* maximum clips per call */
+  int C, T, H, W;        /* clip geometry, reference NCTHW (KTH: C in {1,3}, 32, 120, 160) */
+  int hidden;            /* nb_lstm_units (<= 4) */
+  int layers;            /* lstm_layers */
+  int kernel;            /* conv_kernel_size[0], odd */
+  int stride;            /* conv_stride of the input convolutions */
+  int num_classes;
+  int softmax;           /* add_softmax (CLSTM_4.py:82-83) */
+  int batch_norm;        /* the single shared BatchNorm2d (convolution_lstm.py:85,123) */
+  int out_step;          /* step whose pooled top-layer output feeds endFC: the LAST effective
+                            step (CLSTM_4.py:78-80 with use_entire_seq=False) */
+} ivf_clstm_config;
+
+typedef struct ivf_clstm ivf_clstm_t;
+
+/* models/CLSTM_4.Model + models/convolution_lstm.ConvLSTM (forward :96-132, cell :38-48). */
+int ivf_clstm_create(const ivf_clstm_config* cfg, ivf_clstm_t** out);
+void ivf_clstm_destroy(ivf_clstm_t* net);
+size_t ivf_clstm_weights_bytes(const ivf_clstm_t* net);
+size_t ivf_clstm_workspace_bytes(const ivf_clstm_t* net);
+int ivf_clstm_bind(ivf_clstm_t* net, void* weights_arena, void* workspace);
+/* One cell's reference tensors: Wx* [hid][cin][k][k] + bias [hid], Wh* [hid][hid][k][k];
+ * gate order i, f, c, o (convolution_lstm.py:22-29). */
+int ivf_clstm_load_cell(ivf_clstm_t* net, int layer, const float* wxi, const float* wxf, const float* wxc,
+                        const float* wxo, const float* bxi, const float* bxf, const float* bxc,
+                        const float* bxo, const float* whi, const float* whf, const float* whc,
+                        const float* who, ivf_stream_t stream);
+/* clstm.bn.* (NULL when batch_norm == 0) and endFC.{weight [K][feat], bias}. */
+int ivf_clstm_load_head(ivf_clstm_t* net, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                        const float* bn_var, const float* fc_w, const float* fc_b, float bn_eps,
+                        ivf_stream_t stream);
+/* Model.forward, CLSTM_4.py:69-85, on b <= B clips (x NCTHW). */
+int ivf_clstm_forward(ivf_clstm_t* net, const float* x, int b, float* logits, float* probs,
+                      ivf_stream_t stream);
+/* BPTT backward-data of the last forward: dx NCTHW [b,C,T,H,W]. */
+int ivf_clstm_backward(ivf_clstm_t* net, int b, const int* target, const float* dout, float* score, float* dx,
+                       ivf_stream_t stream);
+/* The hot loop (KTH:250-270) with the ConvLSTM backbone; arguments as ivf_i3d_search. */
+int ivf_clstm_search(ivf_clstm_t* net, const float* x, int b, const int* target, float* raw_mask,
+                     float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
+                     float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream);
+int ivf_clstm_perturbed_forward(ivf_clstm_t* net, const float* x, int b, const float* mask, int mode,
+                                float* probs, ivf_stream_t stream);
+
 /* Algorithmic forward FLOPs of all Unit3D convolutions for one clip (2*MAC, real
  * channel counts; backward-data costs the same again).  SURVEY.md section 8d. */
 double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net);

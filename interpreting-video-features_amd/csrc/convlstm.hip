@@ -1,0 +1,662 @@
+// ConvLSTM classifier (reference models/convolution_lstm.py + models/CLSTM_4.py) as
+// explicit forward and backward-DATA (BPTT) kernels, and its mask-search loop.
+//
+// The recurrence is latency-bound (T x layers dependent cell steps, hidden = 4), so
+// the design removes everything that does not have to be sequential:
+//   * the input convolutions Wx*x_t (+bias) of a layer are batched over ALL T steps
+//     in one launch (layer i at step t only needs layer i-1's output at step t);
+//   * one fused kernel per cell step does the 5x5 hidden convolution, the four gates
+//     and the state update (convolution_lstm.py:38-48; the peephole terms are zeros,
+//     :52-54); BatchNorm (ONE shared BN for all layers, :85,123) + MaxPool2d(2) are
+//     batched over T;
+//   * backward mirrors it: one fused kernel per step (Wh^T over dG[t+1] + gate
+//     derivatives), the stride-2 transposed input convolution batched over T.
+// Layout is planar per frame ([.., C, H, W], W fastest): channel counts are 1..16, so
+// coalescing comes from W, and the reference's NCTHW clip is consumed in place.
+// Weights (a few KB) are staged in LDS by every block.
+#include <cstring>
+#include <vector>
+
+#include "ivf_common.h"
+
+namespace ivf {
+
+constexpr int MAXK = 7;
+
+// Gx[b,t,g*hid+j,yo,xo] = bias[g][j] + sum_{c,ky,kx} Wx[g][j][c][ky][kx] * x[b,c,t,yo*s-p+ky,xo*s-p+kx]
+// x addressed by generic strides (elements): b*sB + c*sC + t*sT + y*W + x.
+__global__ __launch_bounds__(256) void clstm_xconv_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ gx, int B, int T, int Cin, int H, int W, long sB, long sC, long sT, int hid, int k,
+    int stride, int Ho, int Wo) {
+  extern __shared__ float sw[];  // [4*hid][Cin][k][k] + [4*hid] bias
+  const int G = 4 * hid;
+  const int nw = G * Cin * k * k;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
+  for (int i = threadIdx.x; i < G; i += blockDim.x) sw[nw + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int pad = (k - 1) / 2;
+  const long total = (long)B * T * Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xo = i % Wo;
+    int yo = (i / Wo) % Ho;
+    int t = (i / ((long)Wo * Ho)) % T;
+    int b = i / ((long)Wo * Ho * T);
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = (o < G) ? sw[nw + o] : 0.f;
+    for (int c = 0; c < Cin; ++c) {
+      const float* xp = x + b * sB + c * sC + t * sT;
+      for (int ky = 0; ky < k; ++ky) {
+        int y = yo * stride - pad + ky;
+        if ((unsigned)y >= (unsigned)H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int xx = xo * stride - pad + kx;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          float v = xp[(long)y * W + xx];
+          const float* wp = sw + (c * k + ky) * k + kx;
+#pragma unroll
+          for (int o = 0; o < 16; ++o)
+            if (o < G) acc[o] += wp[o * Cin * k * k] * v;
+        }
+      }
+    }
+    float* gp = gx + (((long)b * T + t) * G) * Ho * Wo + (long)yo * Wo + xo;
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+      if (o < G) gp[(long)o * Ho * Wo] = acc[o];
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// One cell step for all clips: gates = Gx[t] + Wh * h[t-1]; state update; saves
+// S[b,t,{i,f,g,o,c},j,y,x] and H[b,t,j,y,x].
+__global__ __launch_bounds__(256) void clstm_step_fwd_kernel(
+    const float* __restrict__ gx, const float* __restrict__ wh, float* __restrict__ S, float* __restrict__ Hs,
+    int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  extern __shared__ float sw[];  // [4*hid][hid][k][k]
+  const int G = 4 * hid;
+  const int nw = G * hid * k * k;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = wh[i];
+  __syncthreads();
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xo = i % Wo;
+    int yo = (i / Wo) % Ho;
+    int b = i / plane;
+    const float* gp = gx + (((long)b * T + t) * G) * plane + (long)yo * Wo + xo;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = (o < G) ? gp[(long)o * plane] : 0.f;
+    if (t > 0) {
+      const float* hp = Hs + (((long)b * T + (t - 1)) * hid) * plane;
+      for (int c = 0; c < hid; ++c)
+        for (int ky = 0; ky < k; ++ky) {
+          int y = yo - pad + ky;
+          if ((unsigned)y >= (unsigned)Ho) continue;
+          for (int kx = 0; kx < k; ++kx) {
+            int xx = xo - pad + kx;
+            if ((unsigned)xx >= (unsigned)Wo) continue;
+            float v = hp[(long)c * plane + (long)y * Wo + xx];
+            const float* wp = sw + (c * k + ky) * k + kx;
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+              if (o < G) acc[o] += wp[o * hid * k * k] * v;
+          }
+        }
+    }
+    float* sp = S + (((long)b * T + t) * 5 * hid) * plane + (long)yo * Wo + xo;
+    const float* cprev = (t > 0) ? S + ((((long)b * T + (t - 1)) * 5 + 4) * hid) * plane + (long)yo * Wo + xo : nullptr;
+    float* hp2 = Hs + (((long)b * T + t) * hid) * plane + (long)yo * Wo + xo;
+    for (int j = 0; j < hid; ++j) {
+      float ci = sigmoidf_(acc[j]);
+      float cf = sigmoidf_(acc[hid + j]);
+      float cg = tanhf(acc[2 * hid + j]);
+      float co = sigmoidf_(acc[3 * hid + j]);
+      float cp = cprev ? cprev[(long)j * plane] : 0.f;
+      float cc = cf * cp + ci * cg;
+      float ch = co * tanhf(cc);
+      sp[(long)(0 * hid + j) * plane] = ci;
+      sp[(long)(1 * hid + j) * plane] = cf;
+      sp[(long)(2 * hid + j) * plane] = cg;
+      sp[(long)(3 * hid + j) * plane] = co;
+      sp[(long)(4 * hid + j) * plane] = cc;
+      hp2[(long)j * plane] = ch;
+    }
+  }
+}
+
+// X[b,t,j,yp,xp] = max over 2x2 of (scale[j]*H + shift[j]); first strict maximum wins
+__global__ void clstm_bnpool_fwd_kernel(const float* __restrict__ Hs, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, float* __restrict__ X,
+                                        unsigned char* __restrict__ arg, long n_frames, int hid, int Ho, int Wo,
+                                        int Hp, int Wp) {
+  const long total = n_frames * hid * Hp * Wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xp = i % Wp;
+    int yp = (i / Wp) % Hp;
+    int j = (i / ((long)Wp * Hp)) % hid;
+    long f = i / ((long)Wp * Hp * hid);
+    const float* hp = Hs + (f * hid + j) * (long)Ho * Wo;
+    float sc = scale ? scale[j] : 1.f, sh = shift ? shift[j] : 0.f;
+    float best = 0.f;
+    int bi = 0;
+    for (int q = 0; q < 4; ++q) {
+      float v = hp[(long)(2 * yp + (q >> 1)) * Wo + 2 * xp + (q & 1)] * sc + sh;
+      if (q == 0 || v > best || v != v) { best = v; bi = q; }
+    }
+    X[i] = best;
+    arg[i] = (unsigned char)bi;
+  }
+}
+
+// dHpool[b,t,j,y,x] = scale[j] * dX[pooled cell] if this cell won, else 0
+__global__ void clstm_unpool_bwd_kernel(const float* __restrict__ dX, const unsigned char* __restrict__ arg,
+                                        const float* __restrict__ scale, float* __restrict__ dH, long n_frames,
+                                        int hid, int Ho, int Wo, int Hp, int Wp) {
+  const long total = n_frames * hid * Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int x = i % Wo;
+    int y = (i / Wo) % Ho;
+    long fj = i / ((long)Wo * Ho);
+    int j = fj % hid;
+    int yp = y >> 1, xp = x >> 1;
+    float v = 0.f;
+    if (yp < Hp && xp < Wp) {
+      long pi = (fj * Hp + yp) * Wp + xp;
+      int q = ((y & 1) << 1) | (x & 1);
+      if (arg[pi] == q) v = dX[pi] * (scale ? scale[j] : 1.f);
+    }
+    dH[i] = v;
+  }
+}
+
+// Backward cell step t (convolution_lstm.py:38-48 differentiated):
+// dh = dHpool[t] + Wh^T (x) dG[t+1];  do = dh*tanh(c); dc = dh*o*(1-tanh^2 c) + dC;
+// di = dc*g; df = dc*c_prev; dg = dc*i; dC <- dc*f;  dG = gate derivatives.
+__global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
+    const float* __restrict__ dHpool, const float* __restrict__ wh, const float* __restrict__ S,
+    float* __restrict__ dG, float* __restrict__ dC, int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  extern __shared__ float sw[];
+  const int G = 4 * hid;
+  const int nw = G * hid * k * k;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = wh[i];
+  __syncthreads();
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int x = i % Wo;
+    int y = (i / Wo) % Ho;
+    int b = i / plane;
+    float dh[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < hid; ++j) dh[j] = dHpool[(((long)b * T + t) * hid + j) * plane + (long)y * Wo + x];
+    if (t + 1 < T) {
+      const float* gp = dG + (((long)b * T + (t + 1)) * G) * plane;
+      for (int ky = 0; ky < k; ++ky) {
+        int yy = y - ky + pad;
+        if ((unsigned)yy >= (unsigned)Ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int xx = x - kx + pad;
+          if ((unsigned)xx >= (unsigned)Wo) continue;
+          for (int o = 0; o < G; ++o) {
+            float g = gp[(long)o * plane + (long)yy * Wo + xx];
+            const float* wp = sw + (o * hid * k + ky) * k + kx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < hid) dh[j] += wp[j * k * k] * g;
+          }
+        }
+      }
+    }
+    const float* sp = S + (((long)b * T + t) * 5 * hid) * plane + (long)y * Wo + x;
+    const float* cprev = (t > 0) ? S + ((((long)b * T + (t - 1)) * 5 + 4) * hid) * plane + (long)y * Wo + x : nullptr;
+    float* gout = dG + (((long)b * T + t) * G) * plane + (long)y * Wo + x;
+    float* dcp = dC + ((long)b * hid) * plane + (long)y * Wo + x;
+    for (int j = 0; j < hid; ++j) {
+      float ci = sp[(long)(0 * hid + j) * plane], cf = sp[(long)(1 * hid + j) * plane];
+      float cg = sp[(long)(2 * hid + j) * plane], co = sp[(long)(3 * hid + j) * plane];
+      float cc = sp[(long)(4 * hid + j) * plane];
+      float cp = cprev ? cprev[(long)j * plane] : 0.f;
+      float th = tanhf(cc);
+      float dco = dh[j] * th;
+      float dcc = dh[j] * co * (1.f - th * th) + ((t + 1 < T) ? dcp[(long)j * plane] : 0.f);
+      gout[(long)(0 * hid + j) * plane] = dcc * cg * (ci * (1.f - ci));
+      gout[(long)(1 * hid + j) * plane] = dcc * cp * (cf * (1.f - cf));
+      gout[(long)(2 * hid + j) * plane] = dcc * ci * (1.f - cg * cg);
+      gout[(long)(3 * hid + j) * plane] = dco * (co * (1.f - co));
+      dcp[(long)j * plane] = dcc * cf;
+    }
+  }
+}
+
+// dx[b,c,t,y,x] = sum_{o,ky,kx} Wx[o][c][ky][kx] * dG[b,t,o,(y+p-ky)/s,(x+p-kx)/s]  (exact divisions only)
+__global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
+    const float* __restrict__ dG, const float* __restrict__ w, float* __restrict__ dx, int B, int T, int Cin,
+    int H, int W, long sB, long sC, long sT, int hid, int k, int stride, int Ho, int Wo) {
+  extern __shared__ float sw[];
+  const int G = 4 * hid;
+  const int nw = G * Cin * k * k;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * T * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int x = i % W;
+    int y = (i / W) % H;
+    int t = (i / ((long)W * H)) % T;
+    int b = i / ((long)W * H * T);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* gp = dG + (((long)b * T + t) * G) * plane;
+    for (int ky = 0; ky < k; ++ky) {
+      int ny = y + pad - ky;
+      if (ny < 0 || ny % stride) continue;
+      int yo = ny / stride;
+      if (yo >= Ho) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        int nx = x + pad - kx;
+        if (nx < 0 || nx % stride) continue;
+        int xo = nx / stride;
+        if (xo >= Wo) continue;
+        for (int o = 0; o < G; ++o) {
+          float g = gp[(long)o * plane + (long)yo * Wo + xo];
+          const float* wp = sw + (o * Cin * k + ky) * k + kx;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < Cin) acc[c] += wp[c * k * k] * g;
+        }
+      }
+    }
+    for (int c = 0; c < Cin; ++c) dx[b * sB + c * sC + t * sT + (long)y * W + x] = acc[c];
+  }
+}
+
+__global__ void clstm_fill_kernel(float* p, long n, float v) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// per-clip reverse pairing + NCTHW reverse perturbation (mask.py:24-56) for b masks
+__global__ void clstm_pairs_kernel(const float* __restrict__ mask, int b, int T, float thresh,
+                                   int* __restrict__ partner, float* __restrict__ weight) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const float* m = mask + (long)i * T;
+  int* pr = partner + (long)i * T;
+  float* wt = weight + (long)i * T;
+  int start = -1;
+  for (int j = 0; j <= T; ++j) {
+    bool on = (j < T) && (m[j] > thresh);
+    if (j < T) { pr[j] = j; wt[j] = 0.f; }
+    if (on && start < 0) start = j;
+    if (!on && start >= 0) {
+      int len = j - start;
+      for (int u = 0; u < len / 2; ++u) {
+        int a = start + u, bb = start + len - 1 - u;
+        pr[a] = bb; pr[bb] = a; wt[a] = m[a]; wt[bb] = m[a];
+      }
+      start = -1;
+    }
+  }
+}
+
+__global__ void clstm_reverse_kernel(const float* __restrict__ x, const int* __restrict__ partner,
+                                     const float* __restrict__ weight, float* __restrict__ p, int B, int C, int T,
+                                     int HW) {
+  long total = (long)B * C * T * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int px = i % HW;
+    int t = (i / HW) % T;
+    long bc = i / ((long)HW * T);
+    int b = bc / C;
+    int pt = partner[b * T + t];
+    float v = x[i];
+    if (pt != t) {
+      float w = weight[b * T + t];
+      v = (1.f - w) * v + w * x[(bc * T + pt) * HW + px];
+    }
+    p[i] = v;
+  }
+}
+
+static inline int grid_for(long total, int block = 256, int cap = 4096) {
+  long g = (total + block - 1) / block;
+  return (int)(g > cap ? cap : (g ? g : 1));
+}
+
+struct LayerPlan {
+  int cin, Hin, Win, Ho, Wo, Hp, Wp;
+  size_t wx_off, bx_off, wh_off;                    // floats in weights arena
+  size_t gx_off, S_off, H_off, X_off, dG_off, dHp_off, dC_off, dX_off;  // floats in workspace
+  size_t arg_off;                                   // bytes
+};
+
+}  // namespace ivf
+
+using namespace ivf;
+
+struct ivf_clstm {
+  ivf_clstm_config cfg;
+  std::vector<LayerPlan> L;
+  size_t bn_scale_off, bn_shift_off, fcw_off, fcb_off, weights_floats;
+  int feat;
+  size_t ws_bytes;
+  size_t off_p, off_dp, off_flat, off_dflat, off_logits, off_probs, off_score, off_sig, off_terms, off_dreg,
+      off_dsig, off_fbwd, off_pair;
+  float* wa = nullptr;
+  char* ws = nullptr;
+  std::vector<bool> cell_loaded;
+  bool head_loaded = false;
+  float* wsf(size_t off) const { return (float*)ws + off; }
+  template <class T>
+  T* at(size_t off) const { return (T*)(ws + off); }
+};
+
+extern "C" int ivf_clstm_create(const ivf_clstm_config* c, ivf_clstm_t** out) {
+  IVF_CHECK_ARG(c && out, "clstm_create: null pointer");
+  IVF_CHECK_ARG(c->B > 0 && c->C > 0 && c->C <= 4 && c->T > 0 && c->T <= 64 && c->H > 0 && c->W > 0,
+                "clstm_create: bad clip geometry (C<=4, T<=64)");
+  IVF_CHECK_ARG(c->hidden > 0 && c->hidden <= 4 && c->layers > 0 && c->layers <= 8,
+                "clstm_create: hidden must be 1..4 (reference configs use 4), layers 1..8");
+  IVF_CHECK_ARG(c->kernel >= 1 && c->kernel <= MAXK && (c->kernel & 1) && c->stride >= 1 && c->num_classes > 0,
+                "clstm_create: kernel must be odd <= %d", MAXK);
+  IVF_CHECK_ARG(c->out_step >= 0 && c->out_step < c->T, "clstm_create: out_step outside [0,T)");
+  ivf_clstm* n = new ivf_clstm();
+  n->cfg = *c;
+  const int hid = c->hidden, k = c->kernel, G = 4 * hid;
+  size_t w = 0;
+  auto takew = [&](size_t e) { size_t o = w; w += (e + 63) / 64 * 64; return o; };
+  size_t fl = 0;
+  const size_t B = c->B, T = c->T;
+  auto takef = [&](size_t e) { size_t o = fl; fl += (e + 63) / 64 * 64; return o; };
+  int cin = c->C, H = c->H, W = c->W;
+  for (int i = 0; i < c->layers; ++i) {
+    LayerPlan p{};
+    p.cin = cin; p.Hin = H; p.Win = W;
+    p.Ho = H / c->stride; p.Wo = W / c->stride;      // convolution_lstm.py:58-59 (init_hidden shape)
+    int pad = (k - 1) / 2;
+    int conv_h = (H + 2 * pad - k) / c->stride + 1, conv_w = (W + 2 * pad - k) / c->stride + 1;
+    if (conv_h != p.Ho || conv_w != p.Wo || p.Ho < 2 || p.Wo < 2) {
+      set_error("clstm_create: layer %d: conv output %dx%d != hidden state %dx%d (the reference asserts the same)",
+                i, conv_h, conv_w, p.Ho, p.Wo);
+      delete n;
+      return IVF_ERR_BAD_ARG;
+    }
+    p.Hp = p.Ho / 2; p.Wp = p.Wo / 2;
+    p.wx_off = takew((size_t)G * cin * k * k);
+    p.bx_off = takew(G);
+    p.wh_off = takew((size_t)G * hid * k * k);
+    size_t plane = (size_t)p.Ho * p.Wo;
+    p.gx_off = takef(B * T * G * plane);
+    p.S_off = takef(B * T * 5 * hid * plane);
+    p.H_off = takef(B * T * hid * plane);
+    p.X_off = takef(B * T * hid * p.Hp * p.Wp);
+    p.dG_off = takef(B * T * G * plane);
+    p.dHp_off = takef(B * T * hid * plane);
+    p.dC_off = takef(B * hid * plane);
+    p.dX_off = takef(B * T * hid * p.Hp * p.Wp);
+    n->L.push_back(p);
+    cin = hid; H = p.Hp; W = p.Wp;
+  }
+  n->feat = hid * H * W;
+  n->bn_scale_off = takew(hid);
+  n->bn_shift_off = takew(hid);
+  n->fcw_off = takew((size_t)c->num_classes * n->feat);
+  n->fcb_off = takew(c->num_classes);
+  n->weights_floats = w;
+  size_t clip = (size_t)c->C * c->T * c->H * c->W;
+  n->off_p = takef(B * clip) * 4;
+  n->off_dp = takef(B * clip) * 4;
+  n->off_flat = takef(B * n->feat) * 4;
+  n->off_dflat = takef(B * n->feat) * 4;
+  size_t bytes = fl * 4;
+  auto takeb = [&](size_t nb) { size_t o = bytes; bytes += align_up(nb, 256); return o; };
+  for (auto& p : n->L) p.arg_off = takeb(B * T * hid * p.Hp * p.Wp);
+  const int K = c->num_classes;
+  n->off_logits = takeb(B * K * 4);
+  n->off_probs = takeb(B * K * 4);
+  n->off_score = takeb(B * 4);
+  n->off_sig = takeb(B * T * 4);
+  n->off_terms = takeb(B * 2 * 4);
+  n->off_dreg = takeb(B * T * 4);
+  n->off_dsig = takeb(B * T * 4);
+  n->off_fbwd = takeb(ivf_freeze_bwd_workspace_bytes((int)B, (int)T));
+  n->off_pair = takeb(B * T * 8);
+  n->ws_bytes = bytes;
+  n->cell_loaded.assign(c->layers, false);
+  *out = n;
+  return IVF_OK;
+}
+
+extern "C" void ivf_clstm_destroy(ivf_clstm_t* n) { delete n; }
+extern "C" size_t ivf_clstm_weights_bytes(const ivf_clstm_t* n) { return n ? n->weights_floats * 4 : 0; }
+extern "C" size_t ivf_clstm_workspace_bytes(const ivf_clstm_t* n) { return n ? n->ws_bytes : 0; }
+
+extern "C" int ivf_clstm_bind(ivf_clstm_t* n, void* weights_arena, void* workspace) {
+  IVF_CHECK_ARG(n && weights_arena && workspace, "clstm_bind: null pointer");
+  IVF_CHECK_ARG(((uintptr_t)weights_arena & 255) == 0 && ((uintptr_t)workspace & 255) == 0,
+                "clstm_bind: arenas must be 256-byte aligned");
+  n->wa = (float*)weights_arena;
+  n->ws = (char*)workspace;
+  return IVF_OK;
+}
+
+extern "C" int ivf_clstm_load_cell(ivf_clstm_t* n, int layer, const float* wxi, const float* wxf,
+                                   const float* wxc, const float* wxo, const float* bxi, const float* bxf,
+                                   const float* bxc, const float* bxo, const float* whi, const float* whf,
+                                   const float* whc, const float* who, ivf_stream_t stream) {
+  IVF_CHECK_ARG(n && n->wa, "clstm_load_cell: bind first");
+  IVF_CHECK_ARG(layer >= 0 && layer < (int)n->L.size(), "clstm_load_cell: bad layer");
+  IVF_CHECK_ARG(wxi && wxf && wxc && wxo && bxi && bxf && bxc && bxo && whi && whf && whc && who,
+                "clstm_load_cell: null tensor");
+  const LayerPlan& p = n->L[layer];
+  const int hid = n->cfg.hidden, k = n->cfg.kernel;
+  hipStream_t s = (hipStream_t)stream;
+  const float* wx[4] = {wxi, wxf, wxc, wxo};   // gate order i, f, c(g), o -- convolution_lstm.py:22-29
+  const float* bx[4] = {bxi, bxf, bxc, bxo};
+  const float* wh[4] = {whi, whf, whc, who};
+  size_t ex = (size_t)hid * p.cin * k * k, eh = (size_t)hid * hid * k * k;
+  for (int g = 0; g < 4; ++g) {
+    IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.wx_off + g * ex, wx[g], ex * 4, hipMemcpyDeviceToDevice, s));
+    IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.bx_off + g * hid, bx[g], (size_t)hid * 4, hipMemcpyDeviceToDevice, s));
+    IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.wh_off + g * eh, wh[g], eh * 4, hipMemcpyDeviceToDevice, s));
+  }
+  n->cell_loaded[layer] = true;
+  return IVF_OK;
+}
+
+extern "C" int ivf_clstm_load_head(ivf_clstm_t* n, const float* bn_gamma, const float* bn_beta,
+                                   const float* bn_mean, const float* bn_var, const float* fc_w,
+                                   const float* fc_b, float bn_eps, ivf_stream_t stream) {
+  IVF_CHECK_ARG(n && n->wa, "clstm_load_head: bind first");
+  IVF_CHECK_ARG(fc_w && fc_b, "clstm_load_head: null FC tensors");
+  hipStream_t s = (hipStream_t)stream;
+  if (n->cfg.batch_norm) {
+    IVF_CHECK_ARG(bn_gamma && bn_beta && bn_mean && bn_var, "clstm_load_head: BatchNorm tensors required");
+    IVF_PROPAGATE(ivf_bn_fold(bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, n->wa + n->bn_scale_off,
+                              n->wa + n->bn_shift_off, n->cfg.hidden, s));
+  }
+  IVF_CHECK_HIP(hipMemcpyAsync(n->wa + n->fcw_off, fc_w, (size_t)n->cfg.num_classes * n->feat * 4,
+                               hipMemcpyDeviceToDevice, s));
+  IVF_CHECK_HIP(hipMemcpyAsync(n->wa + n->fcb_off, fc_b, (size_t)n->cfg.num_classes * 4, hipMemcpyDeviceToDevice, s));
+  n->head_loaded = true;
+  return IVF_OK;
+}
+
+namespace ivf {
+
+static int clstm_ready(const ivf_clstm* n, int b) {
+  IVF_CHECK_ARG(n && n->wa && n->ws, "clstm: not bound");
+  IVF_CHECK_ARG(b > 0 && b <= n->cfg.B, "clstm: batch %d outside [1,%d]", b, n->cfg.B);
+  for (bool l : n->cell_loaded) IVF_CHECK_ARG(l, "clstm: a cell's weights are not loaded");
+  IVF_CHECK_ARG(n->head_loaded, "clstm: head weights not loaded");
+  return IVF_OK;
+}
+
+// forward of the clip held at `x` (NCTHW); leaves activations in the workspace
+static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits, float* probs, hipStream_t s) {
+  const ivf_clstm_config& c = n->cfg;
+  const int hid = c.hidden, k = c.kernel, G = 4 * hid, T = c.T;
+  const float* sc = c.batch_norm ? n->wa + n->bn_scale_off : nullptr;
+  const float* sh = c.batch_norm ? n->wa + n->bn_shift_off : nullptr;
+  for (size_t i = 0; i < n->L.size(); ++i) {
+    const LayerPlan& p = n->L[i];
+    const float* in;
+    long sB, sC, sT;
+    if (i == 0) {
+      in = x;
+      sC = (long)T * c.H * c.W; sB = sC * c.C; sT = (long)c.H * c.W;
+    } else {
+      const LayerPlan& q = n->L[i - 1];
+      in = n->wsf(q.X_off);
+      sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
+    }
+    size_t shm = ((size_t)G * p.cin * k * k + G) * 4;
+    hipLaunchKernelGGL(clstm_xconv_fwd_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo)), dim3(256), shm, s, in,
+                       n->wa + p.wx_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
+                       hid, k, c.stride, p.Ho, p.Wo);
+    IVF_CHECK_LAUNCH();
+    size_t shm_h = (size_t)G * hid * k * k * 4;
+    for (int t = 0; t < T; ++t) {
+      hipLaunchKernelGGL(clstm_step_fwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 1024)), dim3(256), shm_h,
+                         s, n->wsf(p.gx_off), n->wa + p.wh_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
+                         p.Ho, p.Wo);
+      IVF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(clstm_bnpool_fwd_kernel, dim3(grid_for((long)b * T * hid * p.Hp * p.Wp)), dim3(256), 0, s,
+                       n->wsf(p.H_off), sc, sh, n->wsf(p.X_off), n->at<unsigned char>(p.arg_off), (long)b * T, hid,
+                       p.Ho, p.Wo, p.Hp, p.Wp);
+    IVF_CHECK_LAUNCH();
+  }
+  // CLSTM_4.py:78-80: endFC on output[-1] (last effective step) flattened [hid*Hp*Wp]
+  const LayerPlan& q = n->L.back();
+  float* flat = n->at<float>(n->off_flat);
+  IVF_CHECK_HIP(hipMemcpy2DAsync(flat, (size_t)n->feat * 4, n->wsf(q.X_off) + (size_t)c.out_step * n->feat,
+                                 (size_t)T * n->feat * 4, (size_t)n->feat * 4, b, hipMemcpyDeviceToDevice, s));
+  float* lg = n->at<float>(n->off_logits);
+  float* pr = n->at<float>(n->off_probs);
+  IVF_PROPAGATE(ivf_head_fwd(flat, n->wa + n->fcw_off, n->wa + n->fcb_off, nullptr, lg, pr, b, 1, n->feat,
+                             c.num_classes, c.softmax, s));
+  size_t nb = (size_t)b * c.num_classes * 4;
+  if (logits) IVF_CHECK_HIP(hipMemcpyAsync(logits, lg, nb, hipMemcpyDeviceToDevice, s));
+  if (probs) IVF_CHECK_HIP(hipMemcpyAsync(probs, pr, nb, hipMemcpyDeviceToDevice, s));
+  return IVF_OK;
+}
+
+// BPTT to the input clip gradient dx (NCTHW)
+static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const float* dout, float* score, float* dx,
+                              hipStream_t s) {
+  const ivf_clstm_config& c = n->cfg;
+  const int hid = c.hidden, k = c.kernel, G = 4 * hid, T = c.T;
+  const float* sc = c.batch_norm ? n->wa + n->bn_scale_off : nullptr;
+  float* flat = n->at<float>(n->off_flat);
+  float* dflat = n->at<float>(n->off_dflat);
+  IVF_PROPAGATE(ivf_head_bwd(flat, n->wa + n->fcw_off, n->at<float>(n->off_probs), target, dout, score, nullptr,
+                             dflat, b, 1, n->feat, c.num_classes, c.softmax, 0, s));
+  // gradient of the pooled top-layer outputs: zero except at out_step
+  const LayerPlan& top = n->L.back();
+  long ntop = (long)b * T * n->feat;
+  hipLaunchKernelGGL(clstm_fill_kernel, dim3(grid_for(ntop)), dim3(256), 0, s, n->wsf(top.dX_off), ntop, 0.f);
+  IVF_CHECK_LAUNCH();
+  IVF_CHECK_HIP(hipMemcpy2DAsync(n->wsf(top.dX_off) + (size_t)c.out_step * n->feat, (size_t)T * n->feat * 4, dflat,
+                                 (size_t)n->feat * 4, (size_t)n->feat * 4, b, hipMemcpyDeviceToDevice, s));
+  for (int i = (int)n->L.size() - 1; i >= 0; --i) {
+    const LayerPlan& p = n->L[i];
+    hipLaunchKernelGGL(clstm_unpool_bwd_kernel, dim3(grid_for((long)b * T * hid * p.Ho * p.Wo)), dim3(256), 0, s,
+                       n->wsf(p.dX_off), n->at<unsigned char>(p.arg_off), sc, n->wsf(p.dHp_off), (long)b * T, hid,
+                       p.Ho, p.Wo, p.Hp, p.Wp);
+    IVF_CHECK_LAUNCH();
+    size_t shm_h = (size_t)G * hid * k * k * 4;
+    for (int t = T - 1; t >= 0; --t) {
+      hipLaunchKernelGGL(clstm_step_bwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 1024)), dim3(256), shm_h,
+                         s, n->wsf(p.dHp_off), n->wa + p.wh_off, n->wsf(p.S_off), n->wsf(p.dG_off),
+                         n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
+      IVF_CHECK_LAUNCH();
+    }
+    float* out;
+    long sB, sC, sT;
+    if (i == 0) {
+      out = dx;
+      sC = (long)T * c.H * c.W; sB = sC * c.C; sT = (long)c.H * c.W;
+    } else {
+      const LayerPlan& q = n->L[i - 1];
+      out = n->wsf(q.dX_off);
+      sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
+    }
+    size_t shm = (size_t)G * p.cin * k * k * 4;
+    hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win)), dim3(256), shm, s,
+                       n->wsf(p.dG_off), n->wa + p.wx_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
+                       c.stride, p.Ho, p.Wo);
+    IVF_CHECK_LAUNCH();
+  }
+  return IVF_OK;
+}
+
+}  // namespace ivf
+
+extern "C" int ivf_clstm_forward(ivf_clstm_t* n, const float* x, int b, float* logits, float* probs,
+                                 ivf_stream_t stream) {
+  IVF_PROPAGATE(clstm_ready(n, b));
+  IVF_CHECK_ARG(x, "clstm_forward: null clip");
+  return clstm_run_forward(n, x, b, logits, probs, (hipStream_t)stream);
+}
+
+extern "C" int ivf_clstm_backward(ivf_clstm_t* n, int b, const int* target, const float* dout, float* score,
+                                  float* dx, ivf_stream_t stream) {
+  IVF_PROPAGATE(clstm_ready(n, b));
+  IVF_CHECK_ARG((target || dout) && dx, "clstm_backward: need target or dout, and dx");
+  return clstm_run_backward(n, b, target, dout, score, dx, (hipStream_t)stream);
+}
+
+extern "C" int ivf_clstm_search(ivf_clstm_t* n, const float* x, int b, const int* target, float* raw_mask,
+                                float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
+                                float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream) {
+  IVF_PROPAGATE(clstm_ready(n, b));
+  IVF_CHECK_ARG(x && target && raw_mask && exp_avg && exp_avg_sq, "clstm_search: null pointer");
+  IVF_CHECK_ARG(N >= 0 && first_step >= 1, "clstm_search: bad iteration counts");
+  const ivf_clstm_config& c = n->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = c.T, HW = c.H * c.W;
+  float* sig = n->at<float>(n->off_sig);
+  float* terms = n->at<float>(n->off_terms);
+  float* dreg = n->at<float>(n->off_dreg);
+  float* dsig = n->at<float>(n->off_dsig);
+  float* score = n->at<float>(n->off_score);
+  float* P = n->at<float>(n->off_p);
+  float* dP = n->at<float>(n->off_dp);
+  for (int it = 0; it < N; ++it) {
+    IVF_PROPAGATE(ivf_mask_reg(raw_mask, b, T, lam1, lam2, sig, terms, dreg, s));
+    IVF_PROPAGATE(ivf_freeze_fwd(x, sig, P, b, c.C, T, HW, 1, 0, s));
+    IVF_PROPAGATE(clstm_run_forward(n, P, b, nullptr, nullptr, s));
+    IVF_PROPAGATE(clstm_run_backward(n, b, target, nullptr, score, dP, s));
+    IVF_PROPAGATE(ivf_freeze_bwd(x, sig, dP, dsig, nullptr, b, c.C, T, HW, 1, 0, n->at<void>(n->off_fbwd), s));
+    IVF_PROPAGATE(ivf_search_step(raw_mask, sig, dsig, dreg, terms, score, exp_avg, exp_avg_sq,
+                                  traj ? traj + (size_t)it * b * 4 : nullptr, b, T, first_step + it, lr, beta1,
+                                  beta2, eps, s));
+  }
+  return IVF_OK;
+}
+
+extern "C" int ivf_clstm_perturbed_forward(ivf_clstm_t* n, const float* x, int b, const float* mask, int mode,
+                                           float* probs, ivf_stream_t stream) {
+  IVF_PROPAGATE(clstm_ready(n, b));
+  IVF_CHECK_ARG(x && mask && (mode == 0 || mode == 1), "clstm_perturbed_forward: bad args");
+  const ivf_clstm_config& c = n->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  float* P = n->at<float>(n->off_p);
+  if (mode == 0) {
+    IVF_PROPAGATE(ivf_freeze_fwd(x, mask, P, b, c.C, c.T, c.H * c.W, 1, 0, s));
+  } else {
+    int* partner = n->at<int>(n->off_pair);
+    float* weight = (float*)(partner + (size_t)c.B * c.T);
+    hipLaunchKernelGGL(clstm_pairs_kernel, dim3(cdiv(b, 64)), dim3(64), 0, s, mask, b, c.T, 0.1f, partner, weight);
+    IVF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clstm_reverse_kernel, dim3(grid_for((long)b * c.C * c.T * c.H * c.W)), dim3(256), 0, s, x,
+                       partner, weight, P, b, c.C, c.T, c.H * c.W);
+    IVF_CHECK_LAUNCH();
+  }
+  return clstm_run_forward(n, P, b, nullptr, probs, s);
+}

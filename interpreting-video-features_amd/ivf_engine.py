@@ -202,3 +202,121 @@ class I3DEngine:
             L.check(L.lib().ivf_i3d_gradcam(self._h, L.ptr(x), b, L.ptr(tgt), 1 if per_frame else 0, oh, ow,
                                             L.ptr(cam), L.ptr(probs), L.stream()))
         return cam, probs
+
+
+class CLSTMEngine:
+    """Plan + arenas for `models.CLSTM_4.Model` (reference CLSTM_4.py:69-85 over
+    convolution_lstm.py:96-132) on `max_batch` clips [C,T,H,W]."""
+
+    def __init__(self, num_classes, clip_shape, max_batch=1, hidden=4, layers=2, kernel=5, stride=2,
+                 softmax=False, batch_norm=True, out_step=None, device=None):
+        L.require_gpu()
+        self.device = torch.device(device if device is not None else "cuda")
+        C, T, H, W = clip_shape
+        cfg = L.CLSTMConfig()
+        cfg.B, cfg.C, cfg.T, cfg.H, cfg.W = int(max_batch), C, T, H, W
+        cfg.hidden, cfg.layers, cfg.kernel, cfg.stride = int(hidden), int(layers), int(kernel), int(stride)
+        cfg.num_classes = int(num_classes)
+        cfg.softmax = 1 if softmax else 0
+        cfg.batch_norm = 1 if batch_norm else 0
+        cfg.out_step = T - 1 if out_step is None else int(out_step)
+        self.cfg = cfg
+        self.clip_shape = (C, T, H, W)
+        self.max_batch = int(max_batch)
+        self.K = int(num_classes)
+        self.layers = int(layers)
+        self._h = c_void_p()
+        L.check(L.lib().ivf_clstm_create(byref(cfg), byref(self._h)))
+        with torch.cuda.device(self.device):
+            self._weights = _arena(L.lib().ivf_clstm_weights_bytes(self._h), self.device)
+            self._ws = _arena(L.lib().ivf_clstm_workspace_bytes(self._h), self.device)
+        L.check(L.lib().ivf_clstm_bind(self._h, L.ptr(self._weights), L.ptr(self._ws)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and L is not None and getattr(L, "_lib", None) is not None:
+            L._lib.ivf_clstm_destroy(h)
+            self._h = c_void_p()
+
+    def load_state_dict(self, sd, bn_eps=1e-5):
+        def get(key):
+            for k in (key, "module." + key):
+                if k in sd:
+                    v = sd[k]
+                    if isinstance(v, np.ndarray):
+                        v = torch.from_numpy(v)
+                    return L.f32c(v.detach().to(self.device))
+            raise KeyError(f"state_dict is missing '{key}'")
+        with torch.cuda.device(self.device):
+            for i in range(self.layers):
+                ts = ([get(f"clstm.cell{i}.Wx{g}.weight") for g in "ifco"]
+                      + [get(f"clstm.cell{i}.Wx{g}.bias") for g in "ifco"]
+                      + [get(f"clstm.cell{i}.Wh{g}.weight") for g in "ifco"])
+                L.check(L.lib().ivf_clstm_load_cell(self._h, i, *[L.ptr(t) for t in ts], L.stream()))
+                torch.cuda.current_stream().synchronize()
+            bn = [get(f"clstm.bn.{k}") for k in ("weight", "bias", "running_mean", "running_var")] \
+                if self.cfg.batch_norm else [None] * 4
+            fw, fb = get("endFC.weight"), get("endFC.bias")
+            L.check(L.lib().ivf_clstm_load_head(self._h, *[L.ptr(t) for t in bn], L.ptr(fw), L.ptr(fb), bn_eps,
+                                                L.stream()))
+            torch.cuda.current_stream().synchronize()
+
+    _clip = I3DEngine._clip
+    _targets = I3DEngine._targets
+    argmax = I3DEngine.argmax
+
+    def forward(self, x, want_logits=False):
+        x = self._clip(x)
+        b = x.shape[0]
+        probs = torch.empty(b, self.K, device=self.device)
+        logits = torch.empty(b, self.K, device=self.device) if want_logits else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_clstm_forward(self._h, L.ptr(x), b, L.ptr(logits), L.ptr(probs), L.stream()))
+        return (probs, logits) if want_logits else probs
+
+    def backward(self, b, target=None, dout=None, want_dx=True):
+        C, T, H, W = self.clip_shape
+        tgt = self._targets(target, b) if target is not None else None
+        dout = L.f32c(dout) if dout is not None else None
+        score = torch.empty(b, device=self.device) if tgt is not None else None
+        dx = torch.empty(b, C, T, H, W, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_clstm_backward(self._h, b, L.ptr(tgt), L.ptr(dout), L.ptr(score), L.ptr(dx),
+                                               L.stream()))
+        return score, dx
+
+    def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
+               state=None, want_traj=True):
+        x = self._clip(x)
+        b = x.shape[0]
+        T = self.clip_shape[1]
+        tgt = self._targets(target, b)
+        L.require_gpu(raw_mask)
+        if raw_mask.dtype != torch.float32 or not raw_mask.is_contiguous() or tuple(raw_mask.shape) != (b, T):
+            raise L.IvfError("raw_mask must be a contiguous float32 [b,T] tensor")
+        if state is None:
+            state = (torch.zeros_like(raw_mask), torch.zeros_like(raw_mask), 0)
+        m, v, done = state
+        traj = torch.empty(N, b, 4, device=self.device) if want_traj else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_clstm_search(self._h, L.ptr(x), b, L.ptr(tgt), L.ptr(raw_mask), L.ptr(m), L.ptr(v),
+                                             lam1, lam2, lr, betas[0], betas[1], eps, int(N), done + 1,
+                                             L.ptr(traj), L.stream()))
+        return traj, (m, v, done + int(N))
+
+    def perturbed_forward(self, x, mask, mode="freeze"):
+        x = self._clip(x)
+        b = x.shape[0]
+        mask = L.f32c(mask.to(self.device))
+        if tuple(mask.shape) != (b, self.clip_shape[1]):
+            raise L.IvfError("mask must be [b,T]")
+        probs = torch.empty(b, self.K, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_clstm_perturbed_forward(self._h, L.ptr(x), b, L.ptr(mask),
+                                                        0 if mode == "freeze" else 1, L.ptr(probs), L.stream()))
+        return probs
+
+    def gradcam(self, *a, **kw):
+        raise L.IvfError("Grad-CAM for the PyTorch ConvLSTM cannot run in the reference either "
+                         "(grad-cam.py:33-49 refers to attributes CLSTM_4.Model lacks, SURVEY.md F5); "
+                         "not built")

@@ -45,7 +45,7 @@ class I3DConfig(Structure):
 class CLSTMConfig(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "C", "T", "H", "W", "hidden", "layers", "kernel", "stride", "num_classes",
-        "softmax", "batch_norm")]
+        "softmax", "batch_norm", "out_step")]
 
 
 _P = c_void_p
@@ -100,7 +100,7 @@ _SIGS = {
                                     POINTER(ctypes.c_double)]),
 }
 
-# entry points added by later translation units; bound when present in _SIGS_OPT
+# csrc/convlstm.hip
 _SIGS_OPT = {
     "ivf_clstm_create": (c_int, [POINTER(CLSTMConfig), POINTER(c_void_p)]),
     "ivf_clstm_destroy": (None, [_P]),
@@ -134,8 +134,6 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         for name, (res, args) in _SIGS_OPT.items():
-            if not hasattr(L, name):   # TODO(convlstm): becomes mandatory with csrc/convlstm.hip
-                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,83 @@
+"""ConvLSTM (CLSTM_4) HIP plan vs the reference model's own outputs
+(tests/golden/clstm.npz, search.npz) at the KTH shapes [B,C,32,120,160]."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(C, B=2, softmax=True):
+    import ivf_engine
+    import ivf_recipe as R
+    eng = ivf_engine.CLSTMEngine(6, (C, 32, 120, 160), max_batch=B, hidden=4, layers=2, kernel=5, stride=2,
+                                 softmax=softmax)
+    eng.load_state_dict(R.clstm_state_dict(channels=C, tag=f'clstm{C}'))
+    return eng
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_clstm_forward_backward(C, golden):
+    import ivf_recipe as R
+    g = golden('clstm')
+    eng = _engine(C)
+    x = torch.from_numpy(np.stack([R.clip(3, C, 32, 120, 160), R.clip(4, C, 32, 120, 160)]) / 255.0).float().cuda()
+    probs, logits = eng.forward(x, want_logits=True)
+    assert rel_err(logits.cpu().numpy(), g[f'c{C}_logits']) < 1e-3
+    assert rel_err(probs.cpu().numpy(), g[f'c{C}_probs']) < 1e-3
+    # upstream gradient of y[0,2] + y[1,4]
+    dout = torch.zeros(2, 6, device='cuda')
+    dout[0, 2] = 1
+    dout[1, 4] = 1
+    _, dx = eng.backward(2, dout=dout)
+    dxn = dx.cpu().numpy()
+    assert rel_err(dxn.ravel()[g[f'c{C}_dx_idx']], g[f'c{C}_dx_val']) < 2e-3
+    assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'c{C}_dx_norm'])) < 1e-3 * float(g[f'c{C}_dx_norm'])
+    assert rel_err(dxn.astype(np.float64).sum(axis=(1, 3, 4)), g[f'c{C}_dx_sum_per_frame']) < 2e-3
+    # one-hot target path gives the same as the explicit dout
+    s, dx2 = eng.backward(2, target=[2, 4])
+    assert torch.equal(dx2, dx)
+    assert abs(float(s[0]) - float(g[f'c{C}_probs'][0, 2])) < 1e-5
+
+
+def test_clstm_search_trajectory(golden):
+    """30 iterations of the hot loop with the KTH lambdas vs the reference harness."""
+    import ivf_recipe as R
+    import ivf_search
+    g = golden('search')
+    eng = _engine(1, B=1)
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None].cuda()
+    probs = eng.forward(x)
+    target = int(torch.argmax(probs[0]))
+    assert target == int(g['c1_target'])
+    tgt = torch.tensor([target], dtype=torch.int32, device='cuda')
+    raw, info = ivf_search.init_masks_central(eng, x, tgt, probs[0, target][None], 0.9, 'freeze')
+    assert abs(float(info['full'][0]) - float(g['c1_full'])) < 1e-5
+    assert np.array_equal(raw[0].cpu().numpy(), g['c1_init'])          # same central mask chosen
+    traj, _ = eng.search(x, [target], raw, 0.02, 0.04, 30)
+    traj = traj[:, 0].cpu().numpy()
+    assert np.max(np.abs(traj - g['c1_traj']) / np.abs(g['c1_traj'])) < 1e-2     # north_star gate
+    assert np.max(np.abs(traj - g['c1_traj']) / np.abs(g['c1_traj'])) < 1e-3     # what we actually get
+    final = torch.sigmoid(raw)[0].cpu().numpy()
+    assert np.max(np.abs(final - g["c1_mask"])) < 1e-2     # Adam(lr=0.2) amplifies last-bit gradient differences
+    assert np.array_equal(np.argsort(-final, kind='stable'), np.argsort(-g['c1_mask'], kind='stable'))
+    rev = eng.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
+    assert abs(float(rev) - float(g['c1_reverse_score'])) < 1e-4
+
+
+def test_clstm_dropin_model(golden):
+    import ivf_recipe as R
+    from models import CLSTM_4
+    g = golden('clstm')
+    m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=3, conv_kernel_size=(5, 5), lstm_layers=2, step=32,
+                      image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31], add_softmax=True)
+    m.load_state_dict(R.to_torch(R.clstm_state_dict(channels=3, tag='clstm3')))
+    m = m.cuda().eval()
+    x = torch.from_numpy(np.stack([R.clip(3, 3, 32, 120, 160), R.clip(4, 3, 32, 120, 160)]) / 255.0).float().cuda()
+    x.requires_grad_()
+    y = m(x)
+    assert rel_err(y.detach().cpu().numpy(), g['c3_probs']) < 1e-3
+    (y[0, 2] + y[1, 4]).backward()
+    assert rel_err(x.grad.cpu().numpy().ravel()[g['c3_dx_idx']], g['c3_dx_val']) < 2e-3

@@ -1,0 +1,151 @@
+"""CPU: the oracle (torch-CPU restatement under oracle/) against outputs of the
+REFERENCE modules themselves (tests/golden/*.npz, made by make_golden.py which
+imports /root/reference).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import ivf_recipe as R
+from conftest import rel_err
+from oracle import clstm_ref, gradcam_ref, i3d_ref, mask_ref
+
+torch.set_num_threads(8)
+
+
+@pytest.mark.parametrize("T", [16, 32])
+def test_freeze_matches_reference(T, golden):
+    g = golden('mask_ops')
+    x = torch.from_numpy(R.uniform(f'g/freeze/x{T}', (2, 3, T, 12, 20), 0, 255)).requires_grad_()
+    m = torch.from_numpy(R.uniform(f'g/freeze/m{T}', (T,), 0, 1)).requires_grad_()
+    gy = torch.from_numpy(R.uniform(f'g/freeze/g{T}', (2, 3, T, 12, 20), -1, 1))
+    p = mask_ref.perturb_sequence(x, m, 'freeze')
+    (p * gy).sum().backward()
+    assert np.array_equal(p.detach().numpy(), g[f'freeze{T}_p'])
+    assert rel_err(m.grad.numpy(), g[f'freeze{T}_dm']) < 1e-5
+    assert rel_err(x.grad.numpy(), g[f'freeze{T}_dx']) < 1e-6
+
+
+@pytest.mark.parametrize("case", ['even_mid', 'odd_mid', 'ends', 'thresh', 'all_on', 'all_off', 'single'])
+def test_reverse_and_submasks_match_reference(case, golden):
+    g = golden('mask_ops')
+    x = torch.from_numpy(R.uniform('g/reverse/x', (2, 3, 16, 6, 10), 0, 255))
+    m = torch.from_numpy(g[f'rev_{case}_mask'])
+    assert np.array_equal(mask_ref.perturb_sequence(x, m, 'reverse').numpy(), g[f'rev_{case}_p'])
+    flat = [-1]
+    for s in mask_ref.find_submasks_from_mask(m, 0.1):
+        flat += s + [-1]
+    assert flat == g[f'rev_{case}_subs'].tolist()
+
+
+def test_snap_matches_reference(golden):
+    g = golden('mask_ops')
+    m = torch.from_numpy(g['snap_in'].copy())
+    xs = torch.from_numpy(R.uniform('g/snap/x', (1, 3, 16, 4, 4), 0, 255))
+    p = mask_ref.perturb_sequence(xs, m, 'freeze', snap_values=True)
+    assert np.array_equal(m.numpy(), g['snap_out']) and np.array_equal(p.numpy(), g['snap_p'])
+
+
+@pytest.mark.parametrize("case", ['rand16', 'rand32', 'mono', 'near_const', 'sig_pm5', 'const'])
+def test_tv_norm_matches_reference(case, golden):
+    g = golden('mask_ops')
+    m = torch.from_numpy(g[f'tv_{case}_in']).requires_grad_()
+    tv = mask_ref.calc_tv_norm(m, 3, 3)
+    tv.backward()
+    assert np.array_equal(tv.detach().numpy(), g[f'tv_{case}_val'])
+    assert np.array_equal(m.grad.numpy(), g[f'tv_{case}_grad'], equal_nan=True)
+
+
+def test_adam_matches_torch_optim(golden):
+    g = golden('mask_ops')
+    p = torch.from_numpy(R.uniform('g/adam/p', (16,), -5, 5))
+    grads = R.uniform('g/adam/g', (12, 16), -1e-2, 1e-2)
+    opt = mask_ref.Adam(p, lr=0.2)
+    traj = [p.numpy().copy()]
+    for gr in grads:
+        opt.step(torch.from_numpy(gr.copy()))
+        traj.append(p.numpy().copy())
+    assert np.allclose(np.array(traj), g['adam_traj'], rtol=1e-6, atol=1e-7)
+
+
+def test_i3d_s16_matches_reference_model(golden):
+    g = golden('i3d')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(7))[None].requires_grad_()
+    eps = {}
+    feat = i3d_ref.features(x, sd, endpoints=eps)
+    feat.retain_grad()
+    logits, probs = i3d_ref.head(feat, sd, (2, 7, 7), True)
+    assert rel_err(logits.detach().numpy(), g['s16_logits']) < 1e-5
+    assert rel_err(probs.detach().numpy(), g['s16_probs']) < 1e-5
+    t = int(probs[0].argmax())
+    assert t == int(g['s16_target'])
+    for n, a in eps.items():
+        assert abs(float(a.detach().double().norm()) - float(g[f's16_norm_{n}'])) < 1e-5 * float(g[f's16_norm_{n}'])
+    probs[0, t].backward()
+    assert rel_err(feat.detach().numpy().ravel()[g['s16_feat_idx']], g['s16_feat_val']) < 1e-5
+    assert rel_err(feat.grad.numpy().ravel()[g['s16_feat_idx']], g['s16_dfeat_val']) < 1e-4
+    assert rel_err(x.grad.numpy().ravel()[g['s16_dx_idx']], g['s16_dx_val']) < 1e-3
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_clstm_matches_reference_model(C, golden):
+    g = golden('clstm')
+    sd = R.to_torch(R.clstm_state_dict(channels=C, tag=f'clstm{C}'))
+    x = torch.from_numpy(np.stack([R.clip(3, C, 32, 120, 160), R.clip(4, C, 32, 120, 160)]) / 255.0).float()
+    x.requires_grad_()
+    y = clstm_ref.forward(x, sd, add_softmax=True)
+    assert rel_err(y.detach().numpy(), g[f'c{C}_probs']) < 1e-5
+    with torch.no_grad():
+        assert rel_err(clstm_ref.forward(x, sd, add_softmax=False).numpy(), g[f'c{C}_logits']) < 1e-5
+    (y[0, 2] + y[1, 4]).backward()
+    assert rel_err(x.grad.numpy().ravel()[g[f'c{C}_dx_idx']], g[f'c{C}_dx_val']) < 1e-4
+    assert rel_err(x.grad.numpy().astype(np.float64).sum(axis=(1, 3, 4)), g[f'c{C}_dx_sum_per_frame']) < 1e-4
+
+
+def test_gradcam_matches_reference(golden):
+    g = golden('gradcam')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(11))[None]
+    for tag, pf in (('pf', True), ('glob', False)):
+        cam, out, _ = gradcam_ref.gradcam_i3d(x, sd, None, normalize_per_frame=pf)
+        assert cam.shape == (16, 224, 224)
+        assert rel_err(out.numpy(), g[f'{tag}_output']) < 1e-5
+        assert np.allclose(cam[:, ::8, ::8], g[f'{tag}_cam_small'], atol=2e-5, equal_nan=True)
+        assert np.allclose(cam[[0, 7, 8, 15]][:, [0, 100, 223]], g[f'{tag}_cam_rows'], atol=2e-5, equal_nan=True)
+    cam, out, ex = gradcam_ref.gradcam_i3d(x, sd, 5, normalize_per_frame=True)
+    assert rel_err(ex['weights'], g['idx5_weights']) < 1e-4
+    assert np.array_equal(np.isnan(cam[:, ::8, ::8]), np.isnan(g['idx5_cam_small']))
+
+
+def test_search_trajectory_matches_reference(golden):
+    """The oracle's search loop (init_mask + Adam loop + reverse score) vs the harness
+    around the reference's mask.py + model + torch.optim.Adam.  CLSTM variant (cheap)."""
+    g = golden('search')
+    sd = R.to_torch(R.clstm_state_dict(channels=1, tag='clstm1'))
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None]
+    target = int(g['c1_target'])
+
+    def score_fn(v):
+        return clstm_ref.forward(v, sd, add_softmax=True)[0, target]
+    res = mask_ref.search_clip(x, score_fn, 0.02, 0.04, 30, 'freeze')
+    assert abs(res['init']['full'] - float(g['c1_full'])) < 1e-6 and abs(res['init']['orig'] - float(g['c1_orig'])) < 1e-6
+    assert np.allclose(res['init']['central'], g['c1_central'], atol=1e-6)
+    assert np.array_equal(torch.where(res['raw_mask'] > 0, 1, 0).numpy() * 0 + (g['c1_init'] > 0), g['c1_init'] > 0)
+    assert np.max(np.abs(res['traj'].numpy() - g['c1_traj']) / np.abs(g['c1_traj'])) < 1e-4
+    assert np.max(np.abs(res['mask'].numpy() - g['c1_mask'])) < 1e-4
+    assert abs(res['reverse_score'] - float(g['c1_reverse_score'])) < 1e-5
+    assert np.array_equal(mask_ref.frame_ranking(res['mask']).numpy(),
+                          np.argsort(-g['c1_mask'], kind='stable'))
+
+
+def test_i3d_search_first_iterations_match_reference(golden):
+    """Two I3D iterations of the oracle loop vs the reference harness (full size)."""
+    g = golden('search')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(21))[None]
+    target = int(g['s16_target'])
+
+    def score_fn(v):
+        return i3d_ref.forward(v, sd)[0, target]
+    res = mask_ref.search_clip(x, score_fn, 0.01, 0.02, 2, 'freeze', init=torch.from_numpy(g['s16_init']))
+    assert np.max(np.abs(res['traj'].numpy() - g['s16_traj'][:2]) / np.abs(g['s16_traj'][:2])) < 1e-4
