@@ -100,6 +100,7 @@ def main():
     import ivf_lib as L
     import ivf_recipe as R
     import ivf_search
+    import ivf_shard
 
     lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
     T, B = args.frames, args.batch
@@ -119,11 +120,7 @@ def main():
     def step(i):
         res = searcher.run(batches[i], labels[i])
         rec = ivf_search.pack_records(clip_ids[i], res, T)
-        if world > 1:
-            gathered = torch.empty(world * rec.shape[0], rec.shape[1], device=dev)
-            dist.all_gather_into_tensor(gathered, rec)
-            return gathered, res
-        return rec, res
+        return ivf_shard.gather_records(rec), res      # one RCCL all_gather when world > 1
 
     def fence():
         if world > 1:

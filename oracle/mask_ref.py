@@ -24,10 +24,12 @@ def freeze(seq, mask):
 
 def find_submasks_from_mask(mask, thresh=0.1):
     """mask.py:60-85: runs of consecutive frames with mask > thresh (strict)."""
-    vals = [float(v) for v in mask]
+    # compare in the mask's own dtype: `mask[j] > thresh` on a float32 tensor rounds the
+    # Python scalar to float32 first (0.1f > 0.1 is False)
+    on = (torch.as_tensor(mask) > thresh).tolist()
     runs, cur = [], None
-    for j, v in enumerate(vals):
-        if v > thresh:
+    for j, v in enumerate(on):
+        if v:
             if cur is None:
                 cur = []
             cur.append(j)
