@@ -31,6 +31,28 @@ VARIANT_NAMES = ("conv3d_igemm_kernel<128,128,2,2>", "conv3d_igemm_kernel<128,64
                  "conv3d_igemm_kernel<128,32,4,1>")
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16)     # a one-GPU box is given a 16-CPU share
+
+
 def cpu_baseline(n_iter_total, sample_iters, lam1, lam2, threads):
     """The CPU oracle (torch fp32 restatement of the reference path, oracle/) on the
     host cores of this box: one clip, init_mask + `sample_iters` iterations + reverse
@@ -51,6 +73,8 @@ def cpu_baseline(n_iter_total, sample_iters, lam1, lam2, threads):
         i3d_ref.forward(x, sd)
         tm, _ = mask_ref.init_mask_central(x, score_fn, 0.9, 'freeze')
     t_init = time.perf_counter() - t0
+    if t_init > 45:            # keep the CPU leg bounded on a slow host
+        sample_iters = min(sample_iters, 2)
     t0 = time.perf_counter()
     res = mask_ref.search_clip(x, score_fn, lam1, lam2, sample_iters, init=tm)   # includes reverse score
     t_loop = time.perf_counter() - t0
@@ -78,7 +102,7 @@ def main():
     ap.add_argument("--iters", type=int, default=300, help="Adam iterations per search (reference N=300)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=5)
+    ap.add_argument("--cpu-sample-iters", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,12 +208,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                pass
-            out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample_iters, lam1, lam2, threads)
+            out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample_iters, lam1, lam2, host_cores())
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if world > 1:
