@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-iters", type=int, default=4)
+    ap.add_argument("--math", choices=["fp32", "bf16x3"], default=None,
+                    help="arithmetic of the Unit3D convolutions (default: ivf_engine.DEFAULT_MATH)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +131,7 @@ def main():
     lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
     T, B = args.frames, args.batch
     eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=B, softmax=True,
-                               stride_mod_layers="" if T == 16 else "none", device=dev)
+                               stride_mod_layers="" if T == 16 else "none", device=dev, math=args.math)
     eng.load_state_dict(R.i3d_state_dict(num_classes=174))
     searcher = ivf_search.MaskSearch(eng, lam1, lam2, args.iters, "freeze", grad_cam_type="guessed",
                                      do_gradcam=True)

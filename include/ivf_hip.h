@@ -93,7 +93,15 @@ int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream);
 
 /* ------------------------------------------------------------------ Unit3D */
 
-/* One convolution as implicit GEMM on the fp32 matrix cores.  Forward of Unit3D
+/* Arithmetic of the implicit-GEMM convolution:
+ *  IVF_MATH_FP32   v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (157 TFLOP/s peak);
+ *  IVF_MATH_BF16X3 every operand split x = hi + lo (two bf16), three
+ *                  v_mfma_f32_32x32x16_bf16 per k-step (lo*hi + hi*lo + hi*hi), fp32
+ *                  accumulate: ~2^-17 relative per product, 5.3x the fp32-MFMA rate. */
+#define IVF_MATH_FP32 0
+#define IVF_MATH_BF16X3 1
+
+/* One convolution as implicit GEMM on the matrix cores.  Forward of Unit3D
  * (models/I3D_doubled.py:83-118: asymmetric zero pad + Conv3d + BN(eval) + ReLU) and,
  * with the packed backward weights, its backward-data.  Channels-last in/out. */
 typedef struct {
@@ -109,6 +117,7 @@ typedef struct {
   int d2s;                     /* depth-to-space output: stride-2 backward-data */
   int dT, dH, dW, dC;          /* d2s: real output dims and channels written */
   int bsT, bsH, bsW;           /* d2s: block strides (forward strides, 1 or 2) */
+  int math;                    /* IVF_MATH_FP32 or IVF_MATH_BF16X3; must match the weight pack */
 } ivf_conv3d_desc;
 
 /* out = epilogue(conv(in, w_packed)): v = acc*scale[n] + shift[n] (NULL = 1 / 0);
@@ -120,9 +129,12 @@ int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float* w_packed,
 int ivf_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                 float* scale, float* shift, int C, ivf_stream_t stream);
 
-/* Reference weight [Cout][Cin][kT][kH][kW] -> forward pack [Cout][taps*CinPad]. */
+/* Reference weight [Cout][Cin][kT][kH][kW] -> forward pack [Cout][taps*CinPad]
+ * (fp32, or two bf16 planes hi/lo with rows padded to 8 for IVF_MATH_BF16X3);
+ * w_packed holds ivf_conv3d_pack_fwd_elems() floats. */
+size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int math);
 int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad, int kT,
-                        int kH, int kW, ivf_stream_t stream);
+                        int kH, int kW, int math, ivf_stream_t stream);
 
 /* Geometry of the backward-data convolution produced by ivf_conv3d_pack_bwd. */
 typedef struct {
@@ -136,10 +148,10 @@ typedef struct {
  * rows*taps_b*Cout floats where taps_b = geom.kT*kH*kW (call with w_packed sized
  * by ivf_conv3d_pack_bwd_elems). */
 size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int sT, int sH, int sW,
-                                 int pT, int pH, int pW);
+                                 int pT, int pH, int pW, int math);
 int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed, int Cout, int Cin,
                         int CinPad, int kT, int kH, int kW, int sT, int sH, int sW, int pT, int pH,
-                        int pW, ivf_conv3d_bwd_geom* geom, ivf_stream_t stream);
+                        int pW, int math, ivf_conv3d_bwd_geom* geom, ivf_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling / head */
 
@@ -194,6 +206,7 @@ typedef struct {
   int pool5a_stride_t;   /* MaxPool3d_5a_2x2 */
   int head_kt, head_kh, head_kw; /* AvgPool3d window: (2,7,7) / (finalTimeLength,4,5) */
   int softmax;           /* Model(softMax=...) */
+  int math;              /* IVF_MATH_FP32 or IVF_MATH_BF16X3 for every Unit3D convolution */
 } ivf_i3d_config;
 
 typedef struct ivf_i3d ivf_i3d_t;

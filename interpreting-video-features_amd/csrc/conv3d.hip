@@ -46,6 +46,10 @@ struct ConvKArgs {
   int dT, dH, dW, dC;
   int bsT, bsH, bsW;  // block strides (the forward conv's strides, 1 or 2)
   int mtiles, ntiles;
+  // split-bf16 (3-pass) mode: weights as two bf16 planes [rows][ldw] (hi, then lo at +w_lo_off)
+  const unsigned short* wbf;
+  int ldw;
+  long w_lo_off;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
@@ -55,6 +59,108 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   int xcd = id & 7, pos = id >> 3;
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + pos;
+}
+
+// Epilogue shared by both arithmetic variants.  Lane holds column n = li of each 32x32 tile,
+// rows (r&3) + 8*(r>>2) + 4*lh.  Per tile all old-value / gate loads are issued before any
+// store (the accumulate path reads and writes the same buffer, which would otherwise
+// serialise every load behind the previous store).
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                              int wn, int li, int lh) {
+  if (a.d2s) {
+    // depth-to-space: n = ((pt*2+ph)*2+pw)*cpad + c with cpad == 4: the 4 channels of one
+    // output pixel sit on 4 consecutive lanes; gather them with quad DPP moves and let the
+    // c == 0 lane store one 16-byte vector.
+    const int cpad = a.Cout >> 3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * 32 + li;
+      const int par = n / cpad, c = n - par * cpad;
+      const int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+      const bool nvalid = n < a.Cout && pt < a.bsT && ph < a.bsH && pw < a.bsW;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][j][r];
+          if (cpad == 4) {
+            int vi = __float_as_int(v);
+            float v0 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x00, 0xf, 0xf, false));
+            float v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x55, 0xf, 0xf, false));
+            float v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xaa, 0xf, 0xf, false));
+            float v3 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xff, 0xf, 0xf, false));
+            if (!nvalid || c != 0 || m >= a.M) continue;
+            int wb = m % a.Wo;
+            int t1 = m / a.Wo;
+            int hb = t1 % a.Ho;
+            int t2 = t1 / a.Ho;
+            int tb = t2 % a.To;
+            int b = t2 / a.To;
+            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
+            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
+            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff;
+            float4 o = make_float4(v0, v1, v2, v3);
+            if (a.accumulate) {
+              float4 old = *reinterpret_cast<const float4*>(a.out + off);
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0) {
+              *reinterpret_cast<float4*>(a.out + off) = o;
+            } else {
+              float ov[4] = {o.x, o.y, o.z, o.w};
+              for (int q = 0; q < a.dC && q < 4; ++q) a.out[off + q] = ov[q];
+            }
+          } else {
+            if (!nvalid || c >= a.dC || m >= a.M) continue;
+            int wb = m % a.Wo;
+            int t1 = m / a.Wo;
+            int hb = t1 % a.Ho;
+            int t2 = t1 / a.Ho;
+            int tb = t2 % a.To;
+            int b = t2 / a.To;
+            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
+            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
+            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff + c;
+            if (a.accumulate) v += a.out[off];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out[off] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + li;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float old[16], gate[16];
+      const int mbase = m0 + wm * (BM / WM) + i * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const bool ok = nvalid && m < a.M;
+        old[r] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
+        gate[r] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (!nvalid || m >= a.M) continue;
+        float v = acc[i][j][r] * sc + sh + old[r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (!(gate[r] > 0.f)) v = 0.f;
+        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -192,64 +298,212 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
     __syncthreads();
   }
 
-  // epilogue: lane holds column n = li, rows (r&3) + 8*(r>>2) + 4*lh
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wm, wn, li, lh);
+}
+
+// ------------------------------------------------------------------ split-bf16 (3-pass) variant
+// fp32-level accuracy on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+// a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (the dropped lo*lo term is 2^-18 relative), each
+// product exact in fp32, fp32 accumulation in the MFMA.  3 x v_mfma_f32_32x32x16_bf16 per 16-deep
+// k-step = 96 cycles against 512 for the fp32 MFMA form.  Activations stay fp32 in HBM and are
+// split while they are staged into LDS; weights are pre-split by the pack kernels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDS_ROW_BF = BK + 8;  // bf16 per LDS row: 80 B rows make the ds_read_b128 fragment reads conflict-free
+
+__device__ __forceinline__ unsigned pk_bf16(float lo_elem, float hi_elem) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
+  return r;
+}
+
+__device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
+  unsigned h01 = pk_bf16(v.x, v.y), h23 = pk_bf16(v.z, v.w);
+  float hx = __uint_as_float(h01 << 16), hy = __uint_as_float(h01 & 0xffff0000u);
+  float hz = __uint_as_float(h23 << 16), hw = __uint_as_float(h23 & 0xffff0000u);
+  *hi = make_uint2(h01, h23);
+  *lo = make_uint2(pk_bf16(v.x - hx, v.y - hy), pk_bf16(v.z - hz, v.w - hw));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int AROWS = BM / 32;
+  constexpr int BROWS = (BN + 63) / 64;   // weight rows each thread stages per plane (8 bf16 per load)
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned short a_hi[BM * LDS_ROW_BF];
+  __shared__ __attribute__((aligned(16))) unsigned short a_lo[BM * LDS_ROW_BF];
+  __shared__ __attribute__((aligned(16))) unsigned short b_hi[BN * LDS_ROW_BF];
+  __shared__ __attribute__((aligned(16))) unsigned short b_lo[BN * LDS_ROW_BF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+  const int mt = tile / a.ntiles;
+  const int nt = tile - mt * a.ntiles;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  const int g = tid & 7;     // A: float4 group of the 32-wide chunk
+  const int r0 = tid >> 3;   //    rows r0 + 32 j
+  const int g2 = tid & 3;    // B: group of 8 bf16
+  const int q0 = tid >> 2;   //    rows q0 + 64 j
+
+  int a_base[AROWS], a_t0[AROWS], a_h0[AROWS], a_w0[AROWS];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / WN) + j * 32 + li;
-    if (n >= a.Cout) continue;
-    float sc = a.scale ? a.scale[n] : 1.f;
-    float sh = a.shift ? a.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= a.M) continue;
-        float v = acc[i][j][r] * sc + sh;
-        size_t off;
-        if (a.d2s) {
-          // m = (b, tb, hb, wb) block; n = ((pt*2+ph)*2+pw)*dCpad + c
-          int wb = m % a.Wo;
-          int t1 = m / a.Wo;
-          int hb = t1 % a.Ho;
-          int t2 = t1 / a.Ho;
-          int tb = t2 % a.To;
-          int b = t2 / a.To;
-          int cpad = a.Cout >> 3;
-          int par = n / cpad, c = n - par * cpad;
-          int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
-          if (pt >= a.bsT || ph >= a.bsH || pw >= a.bsW) continue;
-          int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
-          if (t >= a.dT || h >= a.dH || w >= a.dW || c >= a.dC) continue;
-          off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff + c;
-        } else {
-          off = (size_t)m * a.out_ld + a.out_coff + n;
-        }
-        if (a.accumulate) v += a.out[off];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        if (a.mask) {
-          size_t moff = (size_t)m * a.mask_ld + a.mask_coff + n;
-          if (!(a.mask[moff] > 0.f)) v = 0.f;
-        }
-        a.out[off] = v;
-      }
+  for (int j = 0; j < AROWS; ++j) {
+    int m = m0 + r0 + 32 * j;
+    if (m < a.M) {
+      int wo = m % a.Wo;
+      int t1 = m / a.Wo;
+      int ho = t1 % a.Ho;
+      int t2 = t1 / a.Ho;
+      int to = t2 % a.To;
+      int b = t2 / a.To;
+      a_t0[j] = to * a.sT - a.pT;
+      a_h0[j] = ho * a.sH - a.pH;
+      a_w0[j] = wo * a.sW - a.pW;
+      a_base[j] = b * a.Ti;
+    } else {
+      a_t0[j] = -100000; a_h0[j] = 0; a_w0[j] = 0; a_base[j] = 0;
     }
   }
+  const unsigned short* wrow[BROWS];
+#pragma unroll
+  for (int j = 0; j < BROWS; ++j) {
+    int n = n0 + q0 + 64 * j;
+    wrow[j] = (q0 + 64 * j < BN && n < a.Cout) ? a.wbf + (size_t)n * a.ldw : nullptr;
+  }
+
+  float4 ra[AROWS];
+  uint4 rbh[BROWS], rbl[BROWS];
+  const int khw = a.kH * a.kW;
+
+  auto load_chunk = [&](int k0) {
+    int kk = k0 + 4 * g;
+    bool kvalid = kk < a.K;
+    int tap = kvalid ? kk / a.Cin : 0;
+    int ci = kk - tap * a.Cin;
+    int kt = tap / khw;
+    int rem = tap - kt * khw;
+    int kh = rem / a.kW;
+    int kw = rem - kh * a.kW;
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      int ti = a_t0[j] + kt, hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+      bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
+                (unsigned)wi < (unsigned)a.Wi;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        size_t off = ((size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + ci;
+        v = *reinterpret_cast<const float4*>(a.in + off);
+      }
+      ra[j] = v;
+    }
+    int kb = k0 + 8 * g2;
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+      if (kb < a.ldw && wrow[j]) {
+        h = *reinterpret_cast<const uint4*>(wrow[j] + kb);
+        l = *reinterpret_cast<const uint4*>(wrow[j] + a.w_lo_off + kb);
+      }
+      rbh[j] = h;
+      rbl[j] = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (a.K + BK - 1) / BK;
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      uint2 h, l;
+      split4(ra[j], &h, &l);
+      *reinterpret_cast<uint2*>(&a_hi[(r0 + 32 * j) * LDS_ROW_BF + 4 * g]) = h;
+      *reinterpret_cast<uint2*>(&a_lo[(r0 + 32 * j) * LDS_ROW_BF + 4 * g]) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      if (q0 + 64 * j < BN) {
+        *reinterpret_cast<uint4*>(&b_hi[(q0 + 64 * j) * LDS_ROW_BF + 8 * g2]) = rbh[j];
+        *reinterpret_cast<uint4*>(&b_lo[(q0 + 64 * j) * LDS_ROW_BF + 8 * g2]) = rbl[j];
+      }
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk((c + 1) * BK);
+
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int off = (wm * (BM / WM) + i * 32 + li) * LDS_ROW_BF + ks * 16 + 8 * lh;
+        fah[i] = *reinterpret_cast<const bf16x8*>(&a_hi[off]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(&a_lo[off]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int off = (wn * (BN / WN) + j * 32 + li) * LDS_ROW_BF + ks * 16 + 8 * lh;
+        fbh[j] = *reinterpret_cast<const bf16x8*>(&b_hi[off]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(&b_lo[off]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wm, wn, li, lh);
 }
 
 // ------------------------------------------------------------------ weight packing
 // Reference layout [Cout][Cin][kT][kH][kW] (I3D_doubled.py:64-71) ->
 // forward pack  Wf[co][(tap)*CinP + ci], zero for ci >= Cin (CinP = padded Cin)
+// store one packed weight: fp32, or split into the hi / lo bf16 planes ([rows][ldw] each)
+__device__ __forceinline__ void store_packed(float* out, int math, size_t row, int k, int ldw, size_t rows,
+                                             float v) {
+  if (math == 0) {
+    out[row * ldw + k] = v;
+  } else {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    unsigned h = pk_bf16(v, 0.f) & 0xffffu;
+    float hf = __uint_as_float(h << 16);
+    unsigned l = pk_bf16(v - hf, 0.f) & 0xffffu;
+    o[row * ldw + k] = (unsigned short)h;
+    o[rows * (size_t)ldw + row * ldw + k] = (unsigned short)l;
+  }
+}
+
 __global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout,
-                                int Cin, int CinP, int taps) {
-  size_t total = (size_t)Cout * taps * CinP;
+                                int Cin, int CinP, int taps, int ldw, int math) {
+  size_t total = (size_t)Cout * ldw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    int ci = i % CinP;
-    size_t r = i / CinP;
-    int tap = r % taps;
-    int co = r / taps;
-    out[i] = ci < Cin ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+    int k = i % ldw;
+    int co = i / ldw;
+    int ci = k % CinP;
+    int tap = k / CinP;
+    float v = (tap < taps && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+    store_packed(out, math, co, k, ldw, Cout, v);
   }
 }
 
@@ -257,18 +511,19 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__
 // Wb[ci][(tapf)*Cout + co] = scale[co] * W[co][ci][kT-1-kt][kH-1-kh][kW-1-kw]
 __global__ void pack_bwd_s1_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                    float* __restrict__ out, int Cout, int Cin, int CinRows, int kT,
-                                   int kH, int kW) {
+                                   int kH, int kW, int ldw, int math) {
   int taps = kT * kH * kW;
-  size_t total = (size_t)CinRows * taps * Cout;
+  size_t total = (size_t)CinRows * ldw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    int co = i % Cout;
-    size_t r = i / Cout;
-    int tapf = r % taps;
-    int ci = r / taps;
+    int k = i % ldw;
+    int ci = i / ldw;
+    int co = k % Cout;
+    int tapf = k / Cout;
     int tap = taps - 1 - tapf;  // flipping all three dims == reversing the flat tap index
-    float s = scale ? scale[co] : 1.f;
-    out[i] = ci < Cin ? s * w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+    float v = 0.f;
+    if (tapf < taps && ci < Cin) v = (scale ? scale[co] : 1.f) * w[((size_t)co * Cin + ci) * taps + tap];
+    store_packed(out, math, ci, k, ldw, CinRows, v);
   }
 }
 
@@ -284,16 +539,21 @@ struct D2SPack {
   int oT, oH, oW;     // block-conv front pads (dY index = blk + d - o)
 };
 __global__ void pack_bwd_d2s_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                    float* __restrict__ out, int Cout, int Cin, int CinP, D2SPack p) {
+                                    float* __restrict__ out, int Cout, int Cin, int CinP, D2SPack p, int ldw,
+                                    int math) {
   int taps = p.kT * p.kH * p.kW;
   int btaps = p.KT * p.KH * p.KW;
-  size_t total = (size_t)8 * CinP * btaps * Cout;
+  size_t total = (size_t)8 * CinP * ldw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    int co = i % Cout;
-    size_t r = i / Cout;
-    int bt = r % btaps;
-    int n = r / btaps;
+    int k = i % ldw;
+    int n = i / ldw;
+    int co = k % Cout;
+    int bt = k / Cout;
+    if (bt >= btaps) {
+      store_packed(out, math, n, k, ldw, (size_t)8 * CinP, 0.f);
+      continue;
+    }
     int ci = n % CinP, par = n / CinP;
     int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
     int dw = bt % p.KW, dh = (bt / p.KW) % p.KH, dt = bt / (p.KW * p.KH);
@@ -309,7 +569,7 @@ __global__ void pack_bwd_d2s_kernel(const float* __restrict__ w, const float* __
       int tap = (kt * p.kH + kh) * p.kW + kw;
       v = (scale ? scale[co] : 1.f) * w[((size_t)co * Cin + ci) * taps + tap];
     }
-    out[i] = v;
+    store_packed(out, math, n, k, ldw, (size_t)8 * CinP, v);
   }
 }
 
@@ -326,24 +586,29 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_variant(ConvKArgs& a, hipStream_t s) {
+static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
   const bool timed = prof_begin(s, BN == 128 ? 0 : (BN == 64 ? 1 : 2));
-  hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  if (math == 0)
+    hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
 
-int conv_launch(ConvKArgs& a, hipStream_t s) {
+int conv_launch(ConvKArgs& a, int math, hipStream_t s) {
   // pick BN to minimise padded columns; ties go to the wider tile
   int n128 = cdiv(a.Cout, 128) * 128, n64 = cdiv(a.Cout, 64) * 64, n32 = cdiv(a.Cout, 32) * 32;
-  if (n128 <= n64 && n128 <= n32) return launch_variant<128, 128, 2, 2>(a, s);
-  if (n64 <= n32) return launch_variant<128, 64, 4, 1>(a, s);
-  return launch_variant<128, 32, 4, 1>(a, s);
+  if (n128 <= n64 && n128 <= n32) return launch_variant<128, 128, 2, 2>(a, math, s);
+  if (n64 <= n32) return launch_variant<128, 64, 4, 1>(a, math, s);
+  return launch_variant<128, 32, 4, 1>(a, math, s);
 }
+
+static inline int pack_ldw(int K, int math) { return math ? (K + 7) / 8 * 8 : K; }
 
 // Extent / front offset of the backward conv along one dim.  Input x = s*blk + par
 // receives from outputs o with forward tap k = x + pad - s*o in [0,k): o = blk + d,
@@ -395,6 +660,10 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
   a.K = d->kT * d->kH * d->kW * d->Cin;
   a.M = d->B * d->To * d->Ho * d->Wo;
+  IVF_CHECK_ARG(d->math == 0 || d->math == 1, "conv3d: math must be 0 (fp32 MFMA) or 1 (split-bf16 x3)");
+  a.ldw = pack_ldw(a.K, d->math);
+  a.wbf = reinterpret_cast<const unsigned short*>(w_packed);
+  a.w_lo_off = (long)d->Cout * a.ldw;
   a.relu = d->relu; a.accumulate = d->accumulate; a.d2s = d->d2s;
   a.dT = d->dT; a.dH = d->dH; a.dW = d->dW; a.dC = d->dC;
   a.bsT = d->bsT; a.bsH = d->bsH; a.bsW = d->bsW;
@@ -409,7 +678,8 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   } else {
     IVF_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld, "conv3d: output window outside ld");
   }
-  return conv_launch(a, (hipStream_t)stream);
+  if (d->math == 0) IVF_CHECK_ARG(a.ldw == a.K, "conv3d: internal ldw");
+  return conv_launch(a, d->math, (hipStream_t)stream);
 }
 
 extern "C" int ivf_bn_fold(const float* gamma, const float* beta, const float* mean,
@@ -422,23 +692,30 @@ extern "C" int ivf_bn_fold(const float* gamma, const float* beta, const float* m
   return IVF_OK;
 }
 
+extern "C" size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int math) {
+  return (size_t)Cout * pack_ldw(kT * kH * kW * CinPad, math);
+}
+
 extern "C" int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin,
-                                   int CinPad, int kT, int kH, int kW, ivf_stream_t stream) {
-  IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0,
+                                   int CinPad, int kT, int kH, int kW, int math, ivf_stream_t stream) {
+  IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0 &&
+                    (math == 0 || math == 1),
                 "pack_fwd: bad args");
   int taps = kT * kH * kW;
-  size_t total = (size_t)Cout * taps * CinPad;
+  int ldw = pack_ldw(taps * CinPad, math);
+  size_t total = (size_t)Cout * ldw;
   hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
-                     dim3(256), 0, (hipStream_t)stream, w_ref, w_packed, Cout, Cin, CinPad, taps);
+                     dim3(256), 0, (hipStream_t)stream, w_ref, w_packed, Cout, Cin, CinPad, taps, ldw, math);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
 
 extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed,
                                    int Cout, int Cin, int CinPad, int kT, int kH, int kW, int sT,
-                                   int sH, int sW, int pT, int pH, int pW,
+                                   int sH, int sW, int pT, int pH, int pW, int math,
                                    ivf_conv3d_bwd_geom* geom, ivf_stream_t stream) {
-  IVF_CHECK_ARG(w_ref && w_packed && geom && Cout > 0 && Cout % 4 == 0 && Cin > 0 && CinPad >= Cin,
+  IVF_CHECK_ARG(w_ref && w_packed && geom && Cout > 0 && Cout % 4 == 0 && Cin > 0 && CinPad >= Cin &&
+                    (math == 0 || math == 1),
                 "pack_bwd: bad args (Cout must be a multiple of 4)");
   IVF_CHECK_ARG(sT >= 1 && sT <= 2 && sH >= 1 && sH <= 2 && sW >= 1 && sW <= 2,
                 "pack_bwd: strides must be 1 or 2");
@@ -448,9 +725,10 @@ extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float
     geom->kT = kT; geom->kH = kH; geom->kW = kW;
     geom->pT = kT - 1 - pT; geom->pH = kH - 1 - pH; geom->pW = kW - 1 - pW;
     geom->rows = CinPad;
-    size_t total = (size_t)CinPad * kT * kH * kW * Cout;
+    int ldw = pack_ldw(kT * kH * kW * Cout, math);
+    size_t total = (size_t)CinPad * ldw;
     hipLaunchKernelGGL(pack_bwd_s1_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
-                       dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, kT, kH, kW);
+                       dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, kT, kH, kW, ldw, math);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
@@ -464,19 +742,20 @@ extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float
   geom->kT = p.KT; geom->kH = p.KH; geom->kW = p.KW;
   geom->pT = p.oT; geom->pH = p.oH; geom->pW = p.oW;
   geom->rows = 8 * CinPad;
-  size_t total = (size_t)8 * CinPad * p.KT * p.KH * p.KW * Cout;
+  int ldw = pack_ldw(p.KT * p.KH * p.KW * Cout, math);
+  size_t total = (size_t)8 * CinPad * ldw;
   hipLaunchKernelGGL(pack_bwd_d2s_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
-                     dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, p);
+                     dim3(256), 0, s, w_ref, scale, w_packed, Cout, Cin, CinPad, p, ldw, math);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
 
 extern "C" size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int sT, int sH,
-                                            int sW, int pT, int pH, int pW) {
-  if (sT == 1 && sH == 1 && sW == 1) return (size_t)CinPad * kT * kH * kW * Cout;
+                                            int sW, int pT, int pH, int pW, int math) {
+  if (sT == 1 && sH == 1 && sW == 1) return (size_t)CinPad * pack_ldw(kT * kH * kW * Cout, math);
   int KT, KH, KW, o;
   bwd_span(kT, sT, pT, &KT, &o);
   bwd_span(kH, sH, pH, &KH, &o);
   bwd_span(kW, sW, pW, &KW, &o);
-  return (size_t)8 * CinPad * KT * KH * KW * Cout;
+  return (size_t)8 * CinPad * pack_ldw(KT * KH * KW * Cout, math);
 }

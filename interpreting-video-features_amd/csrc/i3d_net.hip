@@ -221,10 +221,11 @@ static int build_plan(ivf_i3d* n) {
       L.shift_off = take(L.cout);
       continue;
     }
-    L.wf_elems = (size_t)L.cout * taps * L.cinp;
+    (void)taps;
+    L.wf_elems = ivf_conv3d_pack_fwd_elems(L.cout, L.cinp, L.k[0], L.k[1], L.k[2], c.math);
     L.wf_off = take(L.wf_elems);
     L.wb_elems = ivf_conv3d_pack_bwd_elems(L.cout, L.cinp, L.k[0], L.k[1], L.k[2], L.s[0], L.s[1], L.s[2],
-                                           L.pad[0], L.pad[1], L.pad[2]);
+                                           L.pad[0], L.pad[1], L.pad[2], c.math);
     L.wb_off = take(L.wb_elems);
     L.scale_off = take(L.cout);
     L.shift_off = take(L.cout);
@@ -277,6 +278,7 @@ static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->kT = o.k[0]; d->kH = o.k[1]; d->kW = o.k[2]; d->sT = o.s[0]; d->sH = o.s[1]; d->sW = o.s[2];
   d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
   d->relu = 1;
+  d->math = n->cfg.math;
 }
 
 static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
@@ -290,6 +292,7 @@ static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->out_ld = s.C; d->out_coff = o.src_coff;
   d->accumulate = o.bwd_accumulate;
   d->mask_ld = s.C; d->mask_coff = o.src_coff;
+  d->math = n->cfg.math;
   if (L.geom.d2s) {
     d->d2s = 1;
     d->bsT = o.s[0]; d->bsH = o.s[1]; d->bsW = o.s[2];
@@ -464,6 +467,7 @@ extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
   IVF_CHECK_ARG(cfg->stem_stride_t >= 1 && cfg->stem_stride_t <= 2 && cfg->pool4a_stride_t >= 1 &&
                     cfg->pool4a_stride_t <= 2 && cfg->pool5a_stride_t >= 1 && cfg->pool5a_stride_t <= 2,
                 "i3d_create: temporal strides must be 1 or 2");
+  IVF_CHECK_ARG(cfg->math == IVF_MATH_FP32 || cfg->math == IVF_MATH_BF16X3, "i3d_create: unknown math mode");
   ivf_i3d* n = new ivf_i3d();
   n->cfg = *cfg;
   int rc = build_plan(n);
@@ -521,9 +525,11 @@ extern "C" int ivf_i3d_load_conv(ivf_i3d_t* net, int i, const float* w, const fl
   }
   IVF_CHECK_ARG(g && be && mu && var, "i3d_load_conv: unit %s needs BatchNorm tensors", L.name.c_str());
   IVF_PROPAGATE(ivf_bn_fold(g, be, mu, var, eps, A + L.scale_off, A + L.shift_off, L.cout, s));
-  IVF_PROPAGATE(ivf_conv3d_pack_fwd(w, A + L.wf_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1], L.k[2], s));
+  IVF_PROPAGATE(ivf_conv3d_pack_fwd(w, A + L.wf_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1], L.k[2],
+                                    net->cfg.math, s));
   IVF_PROPAGATE(ivf_conv3d_pack_bwd(w, A + L.scale_off, A + L.wb_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1],
-                                    L.k[2], L.s[0], L.s[1], L.s[2], L.pad[0], L.pad[1], L.pad[2], &L.geom, s));
+                                    L.k[2], L.s[0], L.s[1], L.s[2], L.pad[0], L.pad[1], L.pad[2], net->cfg.math,
+                                    &L.geom, s));
   net->loaded[i] = true;
   return IVF_OK;
 }

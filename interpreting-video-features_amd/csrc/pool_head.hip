@@ -87,24 +87,21 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
     int ti = t2 % a.Ti;
     int b = t2 / a.Ti;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    // windows (to) with to*s - p <= ti <= to*s - p + k - 1
-    for (int kt = 0; kt < a.kT; ++kt) {
-      int num = ti + a.pT - kt;
-      if (num < 0 || num % a.sT) continue;
-      int to = num / a.sT;
-      if (to >= a.To) continue;
-      for (int kh = 0; kh < a.kH; ++kh) {
-        int nh = hi + a.pH - kh;
-        if (nh < 0 || nh % a.sH) continue;
-        int ho = nh / a.sH;
-        if (ho >= a.Ho) continue;
-        for (int kw = 0; kw < a.kW; ++kw) {
-          int nw = wi + a.pW - kw;
-          if (nw < 0 || nw % a.sW) continue;
-          int wo = nw / a.sW;
-          if (wo >= a.Wo) continue;
-          int tap = (kt * a.kH + kh) * a.kW + kw;
-          size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+    // windows `to` covering ti: to*s - p <= ti <= to*s - p + k - 1
+    //   => ceil((ti + p - k + 1) / s) <= to <= floor((ti + p) / s), clipped to [0, To)
+    const int nt = ti + a.pT, nh = hi + a.pH, nw = wi + a.pW;
+    const int t_hi = min(nt / a.sT, a.To - 1), t_lo = max((nt - a.kT + a.sT) / a.sT, 0);
+    const int h_hi = min(nh / a.sH, a.Ho - 1), h_lo = max((nh - a.kH + a.sH) / a.sH, 0);
+    const int w_hi = min(nw / a.sW, a.Wo - 1), w_lo = max((nw - a.kW + a.sW) / a.sW, 0);
+    for (int to = t_lo; to <= t_hi; ++to) {
+      const int kt = nt - to * a.sT;
+      for (int ho = h_lo; ho <= h_hi; ++ho) {
+        const int kh = nh - ho * a.sH;
+        const size_t rowo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo;
+        for (int wo = w_lo; wo <= w_hi; ++wo) {
+          const int kw = nw - wo * a.sW;
+          const int tap = (kt * a.kH + kh) * a.kW + kw;
+          const size_t mo = rowo + wo;
           uchar4 u = *reinterpret_cast<const uchar4*>(idx + mo * a.C + 4 * c4);
           float4 g = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + 4 * c4);
           if (u.x == tap) acc[0] += g.x;

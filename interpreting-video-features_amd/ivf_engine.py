@@ -5,6 +5,7 @@ the allocator, nothing more -- and exposes the plan's entry points with torch
 tensors in/out.  Everything that computes is in csrc/*.hip.
 """
 import ctypes
+import os
 from ctypes import byref, c_char, c_int, c_void_p
 
 import numpy as np
@@ -12,6 +13,10 @@ import torch
 
 import ivf_arch as arch
 import ivf_lib as L
+
+
+# arithmetic of the Unit3D convolutions unless a caller overrides it (see include/ivf_hip.h)
+DEFAULT_MATH = os.environ.get("IVF_MATH", "fp32")
 
 
 def _arena(nbytes, device):
@@ -26,7 +31,7 @@ class I3DEngine:
     geometry [C,T,H,W] (reference Model.forward, I3D_doubled.py:351-380)."""
 
     def __init__(self, num_classes, clip_shape, max_batch=1, stride_mod_layers="", last_stride=1,
-                 head_hw=(7, 7), head_time_base=2, softmax=True, device=None):
+                 head_hw=(7, 7), head_time_base=2, softmax=True, device=None, math=None):
         L.require_gpu()
         self.device = torch.device(device if device is not None else "cuda")
         C, T, H, W = clip_shape
@@ -40,6 +45,8 @@ class I3DEngine:
         cfg.head_kt = arch.head_time_kernel(sml, last_stride, head_time_base)
         cfg.head_kh, cfg.head_kw = head_hw
         cfg.softmax = 1 if softmax else 0
+        self.math = math if math is not None else DEFAULT_MATH
+        cfg.math = L.MATH_MODES[self.math]
         self.cfg = cfg
         self.clip_shape = (C, T, H, W)
         self.max_batch = int(max_batch)

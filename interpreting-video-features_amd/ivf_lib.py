@@ -19,11 +19,15 @@ class IvfError(RuntimeError):
     pass
 
 
+MATH_FP32, MATH_BF16X3 = 0, 1
+MATH_MODES = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3}
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "Ti", "Hi", "Wi", "Cin", "in_ld", "in_coff", "To", "Ho", "Wo", "Cout", "out_ld",
         "out_coff", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "relu", "accumulate",
-        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW")]
+        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math")]
 
 
 class BwdGeom(Structure):
@@ -39,7 +43,7 @@ class PoolDesc(Structure):
 class I3DConfig(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "C", "T", "H", "W", "num_classes", "stem_stride_t", "pool4a_stride_t",
-        "pool5a_stride_t", "head_kt", "head_kh", "head_kw", "softmax")]
+        "pool5a_stride_t", "head_kt", "head_kh", "head_kw", "softmax", "math")]
 
 
 class CLSTMConfig(Structure):
@@ -66,9 +70,10 @@ _SIGS = {
     "ivf_sigmoid": (c_int, [_P, _P, _I, _P]),
     "ivf_conv3d": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ivf_bn_fold": (c_int, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
-    "ivf_conv3d_pack_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "ivf_conv3d_pack_bwd_elems": (c_size_t, [_I] * 11),
-    "ivf_conv3d_pack_bwd": (c_int, [_P, _P, _P] + [_I] * 12 + [POINTER(BwdGeom), _P]),
+    "ivf_conv3d_pack_fwd_elems": (c_size_t, [_I] * 6),
+    "ivf_conv3d_pack_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ivf_conv3d_pack_bwd_elems": (c_size_t, [_I] * 12),
+    "ivf_conv3d_pack_bwd": (c_int, [_P, _P, _P] + [_I] * 13 + [POINTER(BwdGeom), _P]),
     "ivf_maxpool3d_fwd": (c_int, [POINTER(PoolDesc), _P, _P, _P, _P]),
     "ivf_maxpool3d_bwd": (c_int, [POINTER(PoolDesc), _P, _P, _P, _P, _I, _P]),
     "ivf_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -43,13 +43,16 @@ def from_cl(y, C):
     return y[..., :C].permute(0, 4, 1, 2, 3).contiguous()
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", list(UNIT_CASES))
-def test_unit3d_fwd_bwd(name, golden):
+def test_unit3d_fwd_bwd(name, math, golden):
     import ivf_arch as arch
     import ivf_lib as L
     import ivf_recipe as R
     lib = L.lib()
     g = golden('units')
+    mm = L.MATH_MODES[math]
+    tol = 1e-5 if math == "fp32" else 1e-4      # split-bf16: ~2^-17 per product
     cin, cout, k, s, thw = UNIT_CASES[name]
     cinp = (cin + 3) // 4 * 4
     B = 2
@@ -67,8 +70,8 @@ def test_unit3d_fwd_bwd(name, golden):
     L.check(lib.ivf_bn_fold(L.ptr(bn[0]), L.ptr(bn[1]), L.ptr(bn[2]), L.ptr(bn[3]), 1e-3, L.ptr(scale),
                             L.ptr(shift), cout, L.stream()))
     taps = k[0] * k[1] * k[2]
-    wf = torch.empty(cout * taps * cinp, device=dev)
-    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(w), L.ptr(wf), cout, cin, cinp, *k, L.stream()))
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cinp, *k, mm), device=dev)
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(w), L.ptr(wf), cout, cin, cinp, *k, mm, L.stream()))
     xcl = to_cl(x, cinp)
     ycl = torch.full((B,) + tuple(outs) + (cout,), float('nan'), device=dev)
     d = L.ConvDesc()
@@ -80,18 +83,19 @@ def test_unit3d_fwd_bwd(name, golden):
     d.sT, d.sH, d.sW = s
     d.pT, d.pH, d.pW = pads
     d.relu = 1
+    d.math = mm
     L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), L.ptr(scale), L.ptr(shift), None,
                            L.ptr(ycl), L.stream()))
     y = from_cl(ycl, cout).cpu().numpy()
-    assert rel_err(y, g[f'unit_{name}_y']) < 1e-5
+    assert rel_err(y, g[f'unit_{name}_y']) < tol
 
     # backward-data: gradient gated by the unit's own ReLU, BN scale folded in the pack
     gate = (ycl > 0).float()
     gcl = (to_cl(gy) * gate).contiguous()
-    n_el = lib.ivf_conv3d_pack_bwd_elems(cout, cinp, *k, *s, *pads)
+    n_el = lib.ivf_conv3d_pack_bwd_elems(cout, cinp, *k, *s, *pads, mm)
     wb = torch.empty(n_el, device=dev)
     geom = L.BwdGeom()
-    L.check(lib.ivf_conv3d_pack_bwd(L.ptr(w), L.ptr(scale), L.ptr(wb), cout, cin, cinp, *k, *s, *pads,
+    L.check(lib.ivf_conv3d_pack_bwd(L.ptr(w), L.ptr(scale), L.ptr(wb), cout, cin, cinp, *k, *s, *pads, mm,
                                     ctypes.byref(geom), L.stream()))
     dxcl = torch.full((B,) + thw + (cinp,), float('nan'), device=dev)
     e = L.ConvDesc()
@@ -101,6 +105,7 @@ def test_unit3d_fwd_bwd(name, golden):
     e.sT = e.sH = e.sW = 1
     e.pT, e.pH, e.pW = geom.pT, geom.pH, geom.pW
     e.out_ld, e.out_coff = cinp, 0
+    e.math = mm
     if geom.d2s:
         e.d2s = 1
         e.bsT, e.bsH, e.bsW = s
@@ -114,7 +119,7 @@ def test_unit3d_fwd_bwd(name, golden):
     L.check(lib.ivf_conv3d(ctypes.byref(e), L.ptr(gcl), L.ptr(wb), None, None, None, L.ptr(dxcl), L.stream()))
     dx = from_cl(dxcl, cin).cpu().numpy()
     assert np.isfinite(dxcl.cpu().numpy()).all()
-    assert rel_err(dx, g[f'unit_{name}_dx']) < 1e-5
+    assert rel_err(dx, g[f'unit_{name}_dx']) < tol
 
 
 @pytest.mark.parametrize("name", list(POOL_CASES))
