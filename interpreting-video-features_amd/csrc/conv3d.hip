@@ -19,149 +19,11 @@
 // staged global -> registers -> LDS ([rows][32+4] floats: the +4 pad makes the
 // ds_read_b128 fragment reads conflict-free), the next chunk's global loads are
 // in flight while the current chunk's MFMAs run.
-#include "ivf_common.h"
+#include <cstdlib>
+
+#include "conv_common.h"
 
 namespace ivf {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
-
-struct ConvKArgs {
-  const float* in;
-  const float* w;
-  float* out;
-  const float* scale;  // [Cout] or null
-  const float* shift;  // [Cout] or null
-  const float* mask;   // ReLU mask source (post-ReLU activation), or null
-  int B, Ti, Hi, Wi, Cin, in_ld, in_coff;
-  int To, Ho, Wo, Cout, out_ld, out_coff;
-  int mask_ld, mask_coff;
-  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
-  int K, M;
-  int relu, accumulate, d2s;
-  // depth-to-space output (stride-2 backward-data as a stride-1 conv over 2x2x2
-  // output blocks): real output dims
-  int dT, dH, dW, dC;
-  int bsT, bsH, bsW;  // block strides (the forward conv's strides, 1 or 2)
-  int mtiles, ntiles;
-  // split-bf16 (3-pass) mode: weights as two bf16 planes [rows][ldw] (hi, then lo at +w_lo_off)
-  const unsigned short* wbf;
-  int ldw;
-  long w_lo_off;
-};
-
-__device__ __forceinline__ int xcd_remap(int id, int nwg) {
-  // Blocks are dealt round-robin over 8 XCDs; give each XCD a contiguous range of
-  // tiles so blocks sharing an A panel share an L2 (bijective form).
-  int q = nwg >> 3, r = nwg & 7;
-  int xcd = id & 7, pos = id >> 3;
-  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + pos;
-}
-
-// Epilogue shared by both arithmetic variants.  Lane holds column n = li of each 32x32 tile,
-// rows (r&3) + 8*(r>>2) + 4*lh.  Per tile all old-value / gate loads are issued before any
-// store (the accumulate path reads and writes the same buffer, which would otherwise
-// serialise every load behind the previous store).
-template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                              int wn, int li, int lh) {
-  if (a.d2s) {
-    // depth-to-space: n = ((pt*2+ph)*2+pw)*cpad + c with cpad == 4: the 4 channels of one
-    // output pixel sit on 4 consecutive lanes; gather them with quad DPP moves and let the
-    // c == 0 lane store one 16-byte vector.
-    const int cpad = a.Cout >> 3;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / WN) + j * 32 + li;
-      const int par = n / cpad, c = n - par * cpad;
-      const int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
-      const bool nvalid = n < a.Cout && pt < a.bsT && ph < a.bsH && pw < a.bsW;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = acc[i][j][r];
-          if (cpad == 4) {
-            int vi = __float_as_int(v);
-            float v0 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x00, 0xf, 0xf, false));
-            float v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x55, 0xf, 0xf, false));
-            float v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xaa, 0xf, 0xf, false));
-            float v3 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xff, 0xf, 0xf, false));
-            if (!nvalid || c != 0 || m >= a.M) continue;
-            int wb = m % a.Wo;
-            int t1 = m / a.Wo;
-            int hb = t1 % a.Ho;
-            int t2 = t1 / a.Ho;
-            int tb = t2 % a.To;
-            int b = t2 / a.To;
-            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
-            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
-            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff;
-            float4 o = make_float4(v0, v1, v2, v3);
-            if (a.accumulate) {
-              float4 old = *reinterpret_cast<const float4*>(a.out + off);
-              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-            }
-            if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            if (a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0) {
-              *reinterpret_cast<float4*>(a.out + off) = o;
-            } else {
-              float ov[4] = {o.x, o.y, o.z, o.w};
-              for (int q = 0; q < a.dC && q < 4; ++q) a.out[off + q] = ov[q];
-            }
-          } else {
-            if (!nvalid || c >= a.dC || m >= a.M) continue;
-            int wb = m % a.Wo;
-            int t1 = m / a.Wo;
-            int hb = t1 % a.Ho;
-            int t2 = t1 / a.Ho;
-            int tb = t2 % a.To;
-            int b = t2 / a.To;
-            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
-            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
-            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff + c;
-            if (a.accumulate) v += a.out[off];
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            a.out[off] = v;
-          }
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / WN) + j * 32 + li;
-    const bool nvalid = n < a.Cout;
-    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
-    const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float old[16], gate[16];
-      const int mbase = m0 + wm * (BM / WM) + i * 32 + 4 * lh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        const bool ok = nvalid && m < a.M;
-        old[r] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
-        gate[r] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (!nvalid || m >= a.M) continue;
-        float v = acc[i][j][r] * sc + sh + old[r];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        if (!(gate[r] > 0.f)) v = 0.f;
-        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
-      }
-    }
-  }
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
@@ -298,7 +160,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
     __syncthreads();
   }
 
-  conv_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wm, wn, li, lh);
+  conv_epilogue<TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
+                        n0 + wn * (BN / WN), li, lh);
 }
 
 // ------------------------------------------------------------------ split-bf16 (3-pass) variant
@@ -307,23 +170,6 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
 // product exact in fp32, fp32 accumulation in the MFMA.  3 x v_mfma_f32_32x32x16_bf16 per 16-deep
 // k-step = 96 cycles against 512 for the fp32 MFMA form.  Activations stay fp32 in HBM and are
 // split while they are staged into LDS; weights are pre-split by the pack kernels.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDS_ROW_BF = BK + 8;  // bf16 per LDS row: 80 B rows make the ds_read_b128 fragment reads conflict-free
-
-__device__ __forceinline__ unsigned pk_bf16(float lo_elem, float hi_elem) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
-  return r;
-}
-
-__device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
-  unsigned h01 = pk_bf16(v.x, v.y), h23 = pk_bf16(v.z, v.w);
-  float hx = __uint_as_float(h01 << 16), hy = __uint_as_float(h01 & 0xffff0000u);
-  float hz = __uint_as_float(h23 << 16), hw = __uint_as_float(h23 & 0xffff0000u);
-  *hi = make_uint2(h01, h23);
-  *lo = make_uint2(pk_bf16(v.x - hx, v.y - hy), pk_bf16(v.z - hz, v.w - hw));
-}
-
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   constexpr int TM = BM / WM / 32;
@@ -472,7 +318,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
     }
     __syncthreads();
   }
-  conv_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wm, wn, li, lh);
+  conv_epilogue<TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
+                        n0 + wn * (BN / WN), li, lh);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -679,6 +526,10 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     IVF_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld, "conv3d: output window outside ld");
   }
   if (d->math == 0) IVF_CHECK_ARG(a.ldw == a.K, "conv3d: internal ldw");
+  static const bool no_halo = getenv("IVF_NO_HALO") != nullptr;   // A/B switch for measurements
+  static const int dbg = getenv("IVF_DBG") ? atoi(getenv("IVF_DBG")) : 0;
+  a.dbg = dbg;
+  if (d->math == 1 && !no_halo && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
 

@@ -1,0 +1,171 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv3d.hip, conv3d_halo.hip).
+#pragma once
+#include "ivf_common.h"
+
+namespace ivf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct ConvKArgs {
+  const float* in;
+  const float* w;
+  float* out;
+  const float* scale;  // [Cout] or null
+  const float* shift;  // [Cout] or null
+  const float* mask;   // ReLU mask source (post-ReLU activation), or null
+  int B, Ti, Hi, Wi, Cin, in_ld, in_coff;
+  int To, Ho, Wo, Cout, out_ld, out_coff;
+  int mask_ld, mask_coff;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+  int K, M;
+  int relu, accumulate, d2s;
+  // depth-to-space output (stride-2 backward-data as a stride-1 conv over 2x2x2
+  // output blocks): real output dims
+  int dT, dH, dW, dC;
+  int bsT, bsH, bsW;  // block strides (the forward conv's strides, 1 or 2)
+  int mtiles, ntiles;
+  // split-bf16 (3-pass) mode: weights as two bf16 planes [rows][ldw] (hi, then lo at +w_lo_off)
+  const unsigned short* wbf;
+  int ldw;
+  long w_lo_off;
+  int dbg;   // ablation switches for measurements (IVF_DBG env; 0 in normal use)
+};
+
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  // Blocks are dealt round-robin over 8 XCDs; give each XCD a contiguous range of
+  // tiles so blocks sharing an A panel share an L2 (bijective form).
+  int q = nwg >> 3, r = nwg & 7;
+  int xcd = id & 7, pos = id >> 3;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDS_ROW_BF = BK + 8;  // bf16 per LDS row: 80 B rows make the ds_read_b128 fragment reads conflict-free
+
+__device__ __forceinline__ unsigned pk_bf16(float lo_elem, float hi_elem) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
+  return r;
+}
+
+__device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
+  unsigned h01 = pk_bf16(v.x, v.y), h23 = pk_bf16(v.z, v.w);
+  float hx = __uint_as_float(h01 << 16), hy = __uint_as_float(h01 & 0xffff0000u);
+  float hz = __uint_as_float(h23 << 16), hw = __uint_as_float(h23 & 0xffff0000u);
+  *hi = make_uint2(h01, h23);
+  *lo = make_uint2(pk_bf16(v.x - hx, v.y - hy), pk_bf16(v.z - hz, v.w - hw));
+}
+
+// Epilogue shared by both arithmetic variants.  Lane holds column n = li of each 32x32 tile,
+// rows (r&3) + 8*(r>>2) + 4*lh.  Per tile all old-value / gate loads are issued before any
+// store (the accumulate path reads and writes the same buffer, which would otherwise
+// serialise every load behind the previous store).
+// `rowmap(local_row)` returns the flattened global output position of a tile row, or -1.
+template <int TM, int TN, class RowMap>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[TM][TN], RowMap rowmap,
+                                              int row_base, int col_base, int li, int lh) {
+  if (a.d2s) {
+    // depth-to-space: n = ((pt*2+ph)*2+pw)*cpad + c with cpad == 4: the 4 channels of one
+    // output pixel sit on 4 consecutive lanes; gather them with quad DPP moves and let the
+    // c == 0 lane store one 16-byte vector.
+    const int cpad = a.Cout >> 3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = col_base + j * 32 + li;
+      const int par = n / cpad, c = n - par * cpad;
+      const int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+      const bool nvalid = n < a.Cout && pt < a.bsT && ph < a.bsH && pw < a.bsW;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = rowmap(row_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+          float v = acc[i][j][r];
+          if (cpad == 4) {
+            int vi = __float_as_int(v);
+            float v0 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x00, 0xf, 0xf, false));
+            float v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0x55, 0xf, 0xf, false));
+            float v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xaa, 0xf, 0xf, false));
+            float v3 = __int_as_float(__builtin_amdgcn_update_dpp(0, vi, 0xff, 0xf, 0xf, false));
+            if (!nvalid || c != 0 || m < 0) continue;
+            int wb = m % a.Wo;
+            int t1 = m / a.Wo;
+            int hb = t1 % a.Ho;
+            int t2 = t1 / a.Ho;
+            int tb = t2 % a.To;
+            int b = t2 / a.To;
+            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
+            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
+            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff;
+            float4 o = make_float4(v0, v1, v2, v3);
+            if (a.accumulate) {
+              float4 old = *reinterpret_cast<const float4*>(a.out + off);
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0) {
+              *reinterpret_cast<float4*>(a.out + off) = o;
+            } else {
+              float ov[4] = {o.x, o.y, o.z, o.w};
+              for (int q = 0; q < a.dC && q < 4; ++q) a.out[off + q] = ov[q];
+            }
+          } else {
+            if (!nvalid || c >= a.dC || m < 0) continue;
+            int wb = m % a.Wo;
+            int t1 = m / a.Wo;
+            int hb = t1 % a.Ho;
+            int t2 = t1 / a.Ho;
+            int tb = t2 % a.To;
+            int b = t2 / a.To;
+            int t = a.bsT * tb + pt, h = a.bsH * hb + ph, w = a.bsW * wb + pw;
+            if (t >= a.dT || h >= a.dH || w >= a.dW) continue;
+            size_t off = ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff + c;
+            if (a.accumulate) v += a.out[off];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out[off] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = col_base + j * 32 + li;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float old[16], gate[16];
+      int mrow[16];
+      const int rbase = row_base + i * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow[r] = rowmap(rbase + (r & 3) + 8 * (r >> 2));
+        const bool ok = nvalid && m >= 0;
+        old[r] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
+        gate[r] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow[r];
+        if (!nvalid || m < 0) continue;
+        float v = acc[i][j][r] * sc + sh + old[r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (!(gate[r] > 0.f)) v = 0.f;
+        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+      }
+    }
+  }
+}
+
+int conv_launch(ConvKArgs& a, int math, hipStream_t s);
+int conv_halo_supported(const ConvKArgs& a);
+int conv_halo_launch(ConvKArgs& a, hipStream_t s);
+
+}  // namespace ivf

@@ -55,7 +55,7 @@ def _check_forward_backward(eng, tag, shape, g):
     # which feeds both sides the same activations.
     dxn = dx.cpu().numpy()
     sample, ref = dxn.ravel()[g[f'{tag}_dx_idx']].astype(np.float64), g[f'{tag}_dx_val'].astype(np.float64)
-    assert np.linalg.norm(sample - ref) / np.linalg.norm(ref) < 3e-2
+    assert np.linalg.norm(sample - ref) / np.linalg.norm(ref) < (3e-2 if eng.math == "fp32" else 5e-2)
     assert rel_err(sample, ref) < 8e-2
     assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
@@ -120,7 +120,7 @@ def _modulewise_backward(eng, sd_np, shape, pool_kernel):
         med = np.median(np.abs(got - refn)) / scale
         assert med < med_tol, (src, med)
         l2 = np.linalg.norm((got - refn).astype(np.float64)) / np.linalg.norm(refn.astype(np.float64))
-        assert l2 < 5e-3, (src, l2)
+        assert l2 < (5e-3 if eng.math == "fp32" else 2e-2), (src, l2)
         worst = max(worst, float(bad.mean()))
     return worst
 

@@ -25,12 +25,12 @@ for n in arch.ENDPOINTS[5:]:
     conv(n+'.b0', cin, oc[0], 1, 1, 1, T, H, W); conv(n+'.b1a', cin, oc[1], 1, 1, 1, T, H, W); conv(n+'.b1b', oc[1], oc[2], 3, 1, 1, T, H, W)
     conv(n+'.b2a', cin, oc[3], 1, 1, 1, T, H, W); conv(n+'.b2b', oc[3], oc[4], 3, 1, 1, T, H, W); pool(n+'.b3a', 3, 3, 1, 1, T, H, W); conv(n+'.b3b', cin, oc[5], 1, 1, 1, T, H, W)
 seq = [('fwd',) + o for o in ops] + [('bwd',) + o for o in reversed(ops)]
-kern = [k for k in it if 'conv3d_igemm' in k[0] or 'maxpool' in k[0]]
+kern = [k for k in it if 'conv3d_' in k[0] or 'maxpool' in k[0]]
 assert len(seq) == len(kern), (len(seq), len(kern))
 tot = totf = pool_t = 0; out = []
 for s, k in zip(seq, kern):
     dur = (k[2] - k[1]) / 1e3; fl = s[2] * B
-    var = k[0].split('<')[1].split('>')[0] if '<' in k[0] else 'pool'
+    var = (('H' if 'halo' in k[0] else '') + k[0].split('<')[1].split('>')[0].replace(' ', '')) if '<' in k[0] else 'pool'
     out.append((dur, s[0], s[1], var, k[3] // 256, fl / dur / 1e6 if fl else 0, s[3] * B, s[4], s[5]))
     if fl: tot += dur; totf += fl
     else: pool_t += dur
