@@ -118,7 +118,17 @@ typedef struct {
   int dT, dH, dW, dC;          /* d2s: real output dims and channels written */
   int bsT, bsH, bsW;           /* d2s: block strides (forward strides, 1 or 2) */
   int math;                    /* IVF_MATH_FP32 or IVF_MATH_BF16X3; must match the weight pack */
+  int variant;                 /* IVF_CONV_AUTO, or a kernel variant id from ivf_conv3d_variants() */
 } ivf_conv3d_desc;
+
+/* Kernel variants: tile shapes of the plain implicit GEMM (IVF_CONV_IGEMM_BASE + 0..2) and of
+ * the LDS-halo kernel (IVF_CONV_HALO_BASE + i; split-bf16, stride 1, 2 <= k <= 4 only).  All
+ * variants compute the same sums; they differ in speed per layer shape and (in the last
+ * bits) in summation order, so a plan fixes one variant per layer. */
+#define IVF_CONV_AUTO 0
+#define IVF_CONV_IGEMM_BASE 1
+#define IVF_CONV_HALO_BASE 16
+int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_ids);
 
 /* out = epilogue(conv(in, w_packed)): v = acc*scale[n] + shift[n] (NULL = 1 / 0);
  * relu_mask != NULL zeroes v where mask <= 0 (the ReLU below, for backward-data). */
@@ -320,6 +330,15 @@ int ivf_clstm_search(ivf_clstm_t* net, const float* x, int b, const int* target,
                      float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream);
 int ivf_clstm_perturbed_forward(ivf_clstm_t* net, const float* x, int b, const float* mask, int mode,
                                 float* probs, ivf_stream_t stream);
+
+/* Per-layer kernel selection.  ivf_i3d_autotune times every candidate variant of every
+ * convolution (forward and backward-data) on `b` clips and keeps the fastest; the result is
+ * 2*ivf_i3d_num_conv_ops() ints that can be read and installed again, e.g. broadcast from
+ * rank 0 so all GPUs of a sharded run use identical kernels (bit-identical per-clip results). */
+int ivf_i3d_num_conv_ops(const ivf_i3d_t* net);
+int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t stream);
+int ivf_i3d_get_tuning(const ivf_i3d_t* net, int* variants_host);
+int ivf_i3d_set_tuning(ivf_i3d_t* net, const int* variants_host);
 
 /* Algorithmic forward FLOPs of all Unit3D convolutions for one clip (2*MAC, real
  * channel counts; backward-data costs the same again).  SURVEY.md section 8d. */

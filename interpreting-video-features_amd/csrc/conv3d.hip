@@ -455,6 +455,16 @@ int conv_launch(ConvKArgs& a, int math, hipStream_t s) {
   return launch_variant<128, 32, 4, 1>(a, math, s);
 }
 
+int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s) {
+  switch (v) {
+    case 0: return launch_variant<128, 128, 2, 2>(a, math, s);
+    case 1: return launch_variant<128, 64, 4, 1>(a, math, s);
+    case 2: return launch_variant<128, 32, 4, 1>(a, math, s);
+  }
+  set_error("conv3d: unknown implicit-GEMM variant %d", v);
+  return IVF_ERR_BAD_ARG;
+}
+
 static inline int pack_ldw(int K, int math) { return math ? (K + 7) / 8 * 8 : K; }
 
 // Extent / front offset of the backward conv along one dim.  Input x = s*blk + par
@@ -529,6 +539,14 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   static const bool no_halo = getenv("IVF_NO_HALO") != nullptr;   // A/B switch for measurements
   static const int dbg = getenv("IVF_DBG") ? atoi(getenv("IVF_DBG")) : 0;
   a.dbg = dbg;
+  if (d->variant != IVF_CONV_AUTO) {
+    // explicit kernel variant (set by the plan's tuner)
+    if (d->variant >= IVF_CONV_HALO_BASE) {
+      IVF_CHECK_ARG(d->math == 1 && conv_halo_supported(a), "conv3d: halo variant needs split-bf16, stride 1, k in 2..4");
+      return conv_halo_launch_variant(a, d->variant - IVF_CONV_HALO_BASE, (hipStream_t)stream);
+    }
+    return conv_igemm_launch_variant(a, d->math, d->variant - IVF_CONV_IGEMM_BASE, (hipStream_t)stream);
+  }
   if (d->math == 1 && !no_halo && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
@@ -609,4 +627,16 @@ extern "C" size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH
   bwd_span(kH, sH, pH, &KH, &o);
   bwd_span(kW, sW, pW, &KW, &o);
   return (size_t)8 * CinPad * pack_ldw(KT * KH * KW * Cout, math);
+}
+
+// candidate kernel variants for a descriptor: fills ids[], returns the count
+extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_ids) {
+  if (!d || !ids) return 0;
+  int n = 0;
+  for (int v = 0; v < 3 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
+  ConvKArgs a{};
+  a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
+  if (d->math == 1 && conv_halo_supported(a))
+    for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
+  return n;
 }

@@ -17,14 +17,42 @@ namespace ivf {
 constexpr int TH = 8, TW = 8;
 constexpr int ROWB = LDS_ROW_BF * 2;  // 80 bytes per LDS row per plane
 
-template <int TT, int BN, int WROWS, int WCOLS>
-__global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * 64) void conv3d_halo_kernel(ConvKArgs a, int tilesT,
-                                                                                           int tilesH, int tilesW) {
+// Position (h, w) inside the 8 x 8 plane of a tile for plane-row p in [0,64): two 32-row MFMA
+// tiles (4 h-rows x 8 w each).  Which lane bit feeds which coordinate bit is free as long as
+// the A operand and the epilogue agree; the choice per halo width minimises LDS bank conflicts
+// of the 16-byte fragment reads (rows are 80 B apart; 3-way with the natural order, 2-way so).
+__device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
+  // hw_pitch == 0 selects the natural order (ablation switch)
+  const int b0 = p & 1, b1 = (p >> 1) & 1, b2 = (p >> 2) & 1, b3 = (p >> 3) & 1, b4 = (p >> 4) & 1;
+  const int half = p >> 5;
+  int hl, ww;
+  if (hw_pitch == 10) {          // k = 3
+    ww = b0 | (b2 << 1) | (b1 << 2);
+    hl = b3 | (b4 << 1);
+  } else if (hw_pitch == 11) {   // k = 4
+    ww = b0 | (b2 << 1) | (b3 << 2);
+    hl = b1 | (b4 << 1);
+  } else {
+    ww = p & 7;
+    hl = (p >> 3) & 3;
+  }
+  *h = half * 4 + hl;
+  *w = ww;
+}
+
+// KS = 2 splits the taps of a chunk between two groups of waves (each wave then owns a
+// bigger output sub-tile, i.e. fewer LDS fragment reads per MFMA: what narrow outputs such as
+// the stem's 32-column backward-data need); the two partial sums meet in LDS at the end.
+template <int TT, int BN, int WROWS, int WCOLS, int KS>
+__global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
+                                                                                                int tilesT,
+                                                                                                int tilesH,
+                                                                                                int tilesW) {
   constexpr int BM = TT * TH * TW;
   constexpr int WM = BM / WROWS, WN = BN / WCOLS;
-  constexpr int NT = WM * WN * 64;
+  constexpr int NT = WM * WN * KS * 64;
   constexpr int TM = WROWS / 32, TN = WCOLS / 32;
-  constexpr int BLOADS = (BN * 4 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per tap
+  constexpr int BLOADS = (KS * BN * 4 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HT = TT + a.kT - 1, HH = TH + a.kH - 1, HW = TW + a.kW - 1;
@@ -32,12 +60,13 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * 64) void conv3d_
   unsigned char* a_hi = smem;
   unsigned char* a_lo = smem + (size_t)HR * ROWB;
   unsigned char* b_base = smem + (size_t)2 * HR * ROWB;   // [2 buffers][hi, lo][BN rows]
-  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * BN * ROWB);   // [HR] input offset of a halo row / in_ld, or -1
+  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * KS * BN * ROWB);   // [HR] input offset of a halo row / in_ld, or -1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN);               // tap group of this wave
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
 
   // tile decode: n-tile fastest, then w, h, t, b
@@ -58,9 +87,12 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * 64) void conv3d_
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int r = wm * WROWS + i * 32 + li;
-    arow[i] = ((r >> 6) * HH + ((r >> 3) & 7)) * HW + (r & 7);
+    int ph, pw;
+    tile_hw(r & 63, (a.dbg & 128) ? 0 : HW, &ph, &pw);
+    arow[i] = ((r >> 6) * HH + ph) * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
+  const int nsteps = (ntaps + KS - 1) / KS;      // tap group g handles taps [g*nsteps, (g+1)*nsteps)
   const int khw = a.kH * a.kW;
   // halo row -> input position (decoded once; the chunk loop only adds the channel offset)
   for (int row = tid; row < HR; row += NT) {
@@ -86,15 +118,18 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * 64) void conv3d_
   // a double-buffered LDS tile.
   constexpr int PF = 3;
   uint4 rbh[PF][BLOADS], rbl[PF][BLOADS];
-  auto load_b = [&](int slot, int tap, int c0) {
+  auto load_b = [&](int slot, int step, int c0) {
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
       int idx = tid + q * NT;
-      int row = idx >> 2, g2 = idx & 3;
+      int grp = idx / (BN * 4);
+      int rem = idx - grp * (BN * 4);
+      int row = rem >> 2, g2 = rem & 3;
+      int tap = step + grp * nsteps;
       int n = n0 + row;
       int c = c0 + 8 * g2;
       uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-      if (row < BN && n < a.Cout && c < a.Cin) {
+      if (grp < KS && tap < ntaps && n < a.Cout && c < a.Cin) {
         const unsigned short* p = a.wbf + (size_t)n * a.ldw + (size_t)tap * a.Cin + c;
         h = *reinterpret_cast<const uint4*>(p);
         l = *reinterpret_cast<const uint4*>(p + a.w_lo_off);
@@ -104,134 +139,283 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * 64) void conv3d_
     }
   };
   auto store_b = [&](int slot, int buf) {
-    unsigned char* bh = b_base + (size_t)buf * 2 * BN * ROWB;
-    unsigned char* bl = bh + (size_t)BN * ROWB;
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
       int idx = tid + q * NT;
-      int row = idx >> 2, g2 = idx & 3;
-      if (row < BN) {
+      int grp = idx / (BN * 4);
+      int rem = idx - grp * (BN * 4);
+      int row = rem >> 2, g2 = rem & 3;
+      if (grp < KS) {
+        unsigned char* bh = b_base + (size_t)(buf * KS + grp) * 2 * BN * ROWB;
+        unsigned char* bl = bh + (size_t)BN * ROWB;
         *reinterpret_cast<uint4*>(bh + row * ROWB + 16 * g2) = rbh[slot][q];
         *reinterpret_cast<uint4*>(bl + row * ROWB + 16 * g2) = rbl[slot][q];
       }
     }
   };
-  auto mma_tap = [&](int tap, int buf, int nks) {
+  // A fragments do not depend on the per-tap barrier (the halo is static within a chunk), so
+  // the 8-wave variants keep the NEXT tap's A fragments in flight under this tap's MFMAs and
+  // read both k-steps of a tap up front: one exposed LDS latency per tap (the weight
+  // fragments) instead of two full ones.  The 16-wave variants have no registers for that.
+  constexpr bool PIPE = false;   // measured slower (register arrays spill to scratch); kept for later tuning
+  bf16x8 pah[2][TM], pal[2][TM];   // prefetched A fragments of the upcoming tap, both k-steps
+  auto tap_offset = [&](int tap) {
     const int kt = tap / khw;
     const int rem = tap - kt * khw;
     const int kh = rem / a.kW;
     const int kw = rem - kh * a.kW;
-    const int toff = ((kt * HH + kh) * HW + kw) * ROWB;
-    const unsigned char* bh = b_base + (size_t)buf * 2 * BN * ROWB;
-    const unsigned char* bl = bh + (size_t)BN * ROWB;
-    for (int ks = 0; ks < nks; ++ks) {
-      bf16x8 fah[TM], fal[TM];
+    return ((kt * HH + kh) * HW + kw) * ROWB;
+  };
+  auto load_a = [&](int step) {
+    const int tap = step + wk * nsteps;
+    if (tap >= ntaps) return;
+    const int toff = tap_offset(tap);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        int off = (a.dbg & 2) ? 16 * lh : arow[i] * ROWB + toff + ks * 32 + 16 * lh;
-        fah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        fal[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+        int off = arow[i] * ROWB + toff + ks * 32 + 16 * lh;
+        pah[ks][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+        pal[ks][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
       }
+  };
+  auto mma_tap = [&](int step, int buf, int nks) {
+    const int tap = step + wk * nsteps;
+    if (tap >= ntaps) return;
+    const unsigned char* bh = b_base + (size_t)(buf * KS + wk) * 2 * BN * ROWB;
+    const unsigned char* bl = bh + (size_t)BN * ROWB;
+    if constexpr (PIPE) {
+      bf16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int off = (a.dbg & 4) ? 16 * lh : (wn * WCOLS + j * 32 + li) * ROWB + ks * 32 + 16 * lh;
-        bf16x8 fbh = *reinterpret_cast<const bf16x8*>(bh + off);
-        bf16x8 fbl = *reinterpret_cast<const bf16x8*>(bl + off);
-        if (a.dbg & 1) {   // ablation: no MFMAs, keep the fragment reads alive
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
-          asm volatile("" ::"v"(fbh), "v"(fbl));
-          continue;
+        for (int i = 0; i < TM; ++i) { fah[ks][i] = pah[ks][i]; fal[ks][i] = pal[ks][i]; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int off = (wn * WCOLS + j * 32 + li) * ROWB + ks * 32 + 16 * lh;
+          fbh[ks][j] = *reinterpret_cast<const bf16x8*>(bh + off);
+          fbl[ks][j] = *reinterpret_cast<const bf16x8*>(bl + off);
         }
+      }
+      if (step + 1 < nsteps) load_a(step + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks < nks) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbl[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+    } else {
+      const int toff = tap_offset(tap);
+      for (int ks = 0; ks < nks; ++ks) {
+        bf16x8 fah[TM], fal[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh, acc[i][j], 0, 0, 0);
+          int off = arow[i] * ROWB + toff + ks * 32 + 16 * lh;
+          fah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+          fal[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int off = (wn * WCOLS + j * 32 + li) * ROWB + ks * 32 + 16 * lh;
+          bf16x8 fbh = *reinterpret_cast<const bf16x8*>(bh + off);
+          bf16x8 fbl = *reinterpret_cast<const bf16x8*>(bl + off);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh, acc[i][j], 0, 0, 0);
+          }
         }
       }
     }
   };
 
+  // halo staging split in two (issue early / write late): 8 float4 groups per halo row
+  // (16-wave variants have no registers to spare and enough waves to hide the latency: they
+  // stage synchronously in batches of 4 loads)
+  constexpr bool ASYNC = false;   // measured: issuing the next halo early buys nothing and costs 40+ registers
+  constexpr int HRMAX = (TT + 3) * (TH + 3) * (TW + 3);
+  constexpr int NSTG = ASYNC ? (HRMAX * 8 + NT - 1) / NT : 4;
+  float4 stg[NSTG];
+  const int ngroups = HR * 8;
+  int stage_base = 0;
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+      int idx = stage_base + u * NT + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < ngroups) {
+        int row = idx >> 3, g = idx & 7;
+        int c = c0 + 4 * g;
+        int pos = rowoff[row];
+        if (pos >= 0 && c < a.Cin && !(a.dbg & 512))
+          v = *reinterpret_cast<const float4*>(a.in + (size_t)pos * a.in_ld + a.in_coff + c);
+      }
+      stg[u] = v;
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+      int idx = stage_base + u * NT + tid;
+      if (idx < ngroups) {
+        int dst = (idx >> 3) * ROWB + 8 * (idx & 7);
+        uint2 h, l;
+        split4(stg[u], &h, &l);
+        *reinterpret_cast<uint2*>(a_hi + dst) = h;
+        *reinterpret_cast<uint2*>(a_lo + dst) = l;
+      }
+    }
+  };
+  __syncthreads();   // rowoff table is complete
+
   for (int c0 = 0; c0 < a.Cin; c0 += BK) {
     // weight tiles of the first PF taps start flying before the halo is staged
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-      if (u < ntaps) load_b(u, u, c0);
+      if (u < nsteps) load_b(u, u, c0);
+    const bool async = ASYNC && !(a.dbg & 64);
+    if (async && c0 == 0) stage_load(0);
     __syncthreads();   // everyone is done with the previous chunk's halo and weight buffers
-    // ---- stage the halo for channels [c0, c0+32): 8 float4 groups per row
-    const int ngroups = HR * 8;
-    for (int base = 0; base < ngroups; base += 4 * NT) {
-      float4 v[4];
-      int dst[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int idx = base + u * NT + tid;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[u] = -1;
-        if (idx < ngroups) {
-          int row = idx >> 3, g = idx & 7;
-          int c = c0 + 4 * g;
-          int pos = rowoff[row];
-          dst[u] = row * ROWB + 8 * g;
-          if (pos >= 0 && c < a.Cin)
-            v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)pos * a.in_ld + a.in_coff + c);
-        }
+    if (async) {
+      stage_store();
+    } else if (ASYNC) {
+      stage_load(c0);
+      stage_store();
+    } else {
+      for (stage_base = 0; stage_base < ngroups; stage_base += NSTG * NT) {
+        stage_load(c0);
+        stage_store();
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (dst[u] >= 0) {
-          uint2 h, l;
-          split4(v[u], &h, &l);
-          *reinterpret_cast<uint2*>(a_hi + dst[u]) = h;
-          *reinterpret_cast<uint2*>(a_lo + dst[u]) = l;
-        }
-      }
+      stage_base = 0;
     }
     store_b(0, 0);
     __syncthreads();
+    if constexpr (PIPE) load_a(0);
+    // the next chunk's halo loads fly under this chunk's MFMAs (registers only; LDS is rewritten
+    // after the barrier that ends the chunk)
+    if (async && c0 + BK < a.Cin) stage_load(c0 + BK);
 
     const int cw = min(BK, a.Cin - c0);
     const int nks = (cw + 15) >> 4;
     // tap loop unrolled by PF so the register ring is statically indexed: at tap (slot u)
     // the LDS buffer tap&1 holds its weights; slot u is refilled with tap+PF, and slot u+1's
     // weights (tap+1, loaded PF-1 taps ago) move to the other LDS buffer after the MFMAs.
-    for (int tap0 = 0; tap0 < ntaps; tap0 += PF) {
+    for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        const int tap = tap0 + u;
-        if (tap < ntaps) {
-          if (tap + PF < ntaps && !(a.dbg & 8)) load_b(u, tap + PF, c0);
+        const int tap = tap0 + u;   // step index within the chunk
+        if (tap < nsteps) {
+          if (tap + PF < nsteps && !(a.dbg & 8)) load_b(u, tap + PF, c0);
           if (!(a.dbg & 32)) mma_tap(tap, tap & 1, nks);
-          if (tap + 1 < ntaps && !(a.dbg & 8)) store_b((u + 1) % PF, (tap + 1) & 1);
+          if (tap + 1 < nsteps && !(a.dbg & 8)) store_b((u + 1) % PF, (tap + 1) & 1);
           if (!(a.dbg & 16)) __syncthreads();
         }
       }
     }
   }
 
+  if constexpr (KS == 2) {
+    // meet the two tap groups: group 1 parks its partial sums in LDS (the halo is dead now),
+    // group 0 adds them and owns the epilogue
+    float* red = reinterpret_cast<float*>(smem);
+    const int slot = (wm * WN + wn) * TM * TN;
+    if (wk == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((slot + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((slot + i * TN + j) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();   // the reduction buffer may be reused below
+  }
+
+  // Depth-to-space output of a full 2x2x2 block conv with 4-channel pixels (the stem's
+  // backward-data): every lane quad holds one 16-byte pixel and a wave's direct stores land as
+  // 32-byte pieces.  Park the tile in LDS as [2TT][16][16][4] and write whole 256-byte pixel
+  // rows instead.
+  if (BN == 32 && a.d2s && a.Cout == 32 && a.bsT == 2 && a.bsH == 2 && a.bsW == 2 && !a.accumulate && !a.relu &&
+      a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && !(a.dbg & 1024)) {
+    float* ot = reinterpret_cast<float*>(smem);
+    if (wk == 0) {
+      const int n = wn * WCOLS + li;          // TN == 1 for BN == 32
+      const int par = n >> 2, c = n & 3;
+      const int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int bh, bw;
+          tile_hw(row & 63, (a.dbg & 128) ? 0 : HW, &bh, &bw);
+          const int tt2 = 2 * (row >> 6) + pt, hh2 = 2 * bh + ph, ww2 = 2 * bw + pw;
+          ot[((tt2 * 16 + hh2) * 16 + ww2) * 4 + c] = acc[i][0][r];
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < 2 * TT * 256; p += NT) {
+      const int t = 2 * t0 + (p >> 8), h = 2 * h0 + ((p >> 4) & 15), w = 2 * w0 + (p & 15);
+      if (t < a.dT && h < a.dH && w < a.dW)
+        *reinterpret_cast<float4*>(a.out + ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff) =
+            *reinterpret_cast<const float4*>(ot + (size_t)p * 4);
+    }
+    return;
+  }
+  if (wk != 0) return;
+
+  if (a.dbg & 256) {   // ablation: no epilogue (a data-dependent store keeps the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 12345.678f) a.out[0] = t;
+    return;
+  }
   conv_epilogue<TM, TN>(
       a, acc,
       [&](int row) {
-        int t = t0 + (row >> 6), h = h0 + ((row >> 3) & 7), w = w0 + (row & 7);
+        int ph, pw;
+        tile_hw(row & 63, (a.dbg & 128) ? 0 : HW, &ph, &pw);
+        int t = t0 + (row >> 6), h = h0 + ph, w = w0 + pw;
         if (t >= a.To || h >= a.Ho || w >= a.Wo) return -1;
         return ((b * a.To + t) * a.Ho + h) * a.Wo + w;
       },
       wm * WROWS, n0 + wn * WCOLS, li, lh);
 }
 
-template <int TT, int BN, int WROWS, int WCOLS>
+template <int TT, int BN, int WROWS, int WCOLS, int KS = 1>
 static int launch_halo(ConvKArgs& a, hipStream_t s) {
-  constexpr int NT = (TT * 64 / WROWS) * (BN / WCOLS) * 64;
+  constexpr int NT = (TT * 64 / WROWS) * (BN / WCOLS) * KS * 64;
   const int HR = (TT + a.kT - 1) * (TH + a.kH - 1) * (TW + a.kW - 1);
-  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * 2 * BN * ROWB + (size_t)HR * sizeof(int);
+  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
+  static_assert(KS == 1 || (size_t)TT * 64 * BN * 4 <= 64 * 1024, "reduction buffer must fit the halo area");
   if (shm > 160 * 1024) {
     set_error("conv3d_halo: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS>),
+    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -240,7 +424,7 @@ static int launch_halo(ConvKArgs& a, hipStream_t s) {
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
   const bool timed = prof_begin(s, BN >= 128 ? 0 : (BN >= 64 ? 1 : 2));
-  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
+  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -253,6 +437,37 @@ int conv_halo_supported(const ConvKArgs& a) {
   return 1;
 }
 
+// Variant table (ivf_conv3d_desc.variant = IVF_CONV_HALO_BASE + index).
+//            TT  BN  wave rows x cols  tap groups
+//  0: 4 192  32 x 96  1      1: 4 128  64 x 64  1     2: 4 128  32 x 64  1     3: 4  96  32 x 96  1
+//  4: 4  64  32 x 64  1      5: 4  64  64 x 64  2     6: 4  32  32 x 32  1     7: 4  32  64 x 32  2
+//  8: 2 192  32 x 96  1      9: 2 128  32 x 64  1    10: 2  96  32 x 96  1    11: 2  64  32 x 64  1
+// 12: 2  32  32 x 32  1     13: 2  64  64 x 64  2    14: 2 128  64 x 64  1
+int conv_halo_num_variants() { return 15; }
+
+int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
+  switch (v) {
+    case 0: return launch_halo<4, 192, 32, 96>(a, s);
+    case 1: return launch_halo<4, 128, 64, 64>(a, s);
+    case 2: return launch_halo<4, 128, 32, 64>(a, s);
+    case 3: return launch_halo<4, 96, 32, 96>(a, s);
+    case 4: return launch_halo<4, 64, 32, 64>(a, s);
+    case 5: return launch_halo<4, 64, 64, 64, 2>(a, s);
+    case 6: return launch_halo<4, 32, 32, 32>(a, s);
+    case 7: return launch_halo<4, 32, 64, 32, 2>(a, s);
+    case 8: return launch_halo<2, 192, 32, 96>(a, s);
+    case 9: return launch_halo<2, 128, 32, 64>(a, s);
+    case 10: return launch_halo<2, 96, 32, 96>(a, s);
+    case 11: return launch_halo<2, 64, 32, 64>(a, s);
+    case 12: return launch_halo<2, 32, 32, 32>(a, s);
+    case 13: return launch_halo<2, 64, 64, 64, 2>(a, s);
+    case 14: return launch_halo<2, 128, 64, 64>(a, s);
+  }
+  set_error("conv3d_halo: unknown variant %d", v);
+  return IVF_ERR_BAD_ARG;
+}
+
+// default choice when the plan has not been tuned
 int conv_halo_launch(ConvKArgs& a, hipStream_t s) {
   // Output-channel tile width: every tile re-stages the halo, so weigh padded columns against
   // the number of tiles (a staging pass costs about as much as ~40 columns of MFMA work).
@@ -264,11 +479,11 @@ int conv_halo_launch(ConvKArgs& a, hipStream_t s) {
   }
   const bool deep = a.To >= 4;   // 4-frame boxes when the map has them, else 2-frame boxes
   switch (best) {
-    case 192: return deep ? launch_halo<4, 192, 32, 96>(a, s) : launch_halo<2, 192, 32, 96>(a, s);
-    case 128: return deep ? launch_halo<4, 128, 64, 64>(a, s) : launch_halo<2, 128, 32, 64>(a, s);
-    case 96: return deep ? launch_halo<4, 96, 32, 96>(a, s) : launch_halo<2, 96, 32, 96>(a, s);
-    case 64: return deep ? launch_halo<4, 64, 32, 64>(a, s) : launch_halo<2, 64, 32, 64>(a, s);
-    default: return deep ? launch_halo<4, 32, 32, 32>(a, s) : launch_halo<2, 32, 32, 32>(a, s);
+    case 192: return conv_halo_launch_variant(a, deep ? 0 : 8, s);
+    case 128: return conv_halo_launch_variant(a, deep ? 1 : 9, s);
+    case 96: return conv_halo_launch_variant(a, deep ? 3 : 10, s);
+    case 64: return conv_halo_launch_variant(a, deep ? 5 : 11, s);
+    default: return conv_halo_launch_variant(a, deep ? 7 : 12, s);
   }
 }
 

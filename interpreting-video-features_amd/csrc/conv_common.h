@@ -165,7 +165,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
 }
 
 int conv_launch(ConvKArgs& a, int math, hipStream_t s);
+int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s);
 int conv_halo_supported(const ConvKArgs& a);
 int conv_halo_launch(ConvKArgs& a, hipStream_t s);
+int conv_halo_num_variants();
+int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s);
 
 }  // namespace ivf

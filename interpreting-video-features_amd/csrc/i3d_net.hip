@@ -44,6 +44,7 @@ struct Op {
   int conv = -1;
   int k[3], s[3], p[3];
   size_t idx_off = 0;  // pool arg-max bytes offset (in bytes, inside workspace)
+  int var_fwd = IVF_CONV_AUTO, var_bwd = IVF_CONV_AUTO;   // tuned kernel variants
   double flops_per_clip = 0.0;  // algorithmic: 2 * out positions * Cout * taps * REAL Cin (same for bwd-data)
   // backward bookkeeping for grad(src)
   bool bwd_accumulate = false, bwd_mask = false;
@@ -279,6 +280,7 @@ static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
   d->relu = 1;
   d->math = n->cfg.math;
+  d->variant = o.var_fwd;
 }
 
 static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
@@ -293,6 +295,7 @@ static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->accumulate = o.bwd_accumulate;
   d->mask_ld = s.C; d->mask_coff = o.src_coff;
   d->math = n->cfg.math;
+  d->variant = o.var_bwd;
   if (L.geom.d2s) {
     d->d2s = 1;
     d->bsT = o.s[0]; d->bsH = o.s[1]; d->bsW = o.s[2];
@@ -676,4 +679,73 @@ extern "C" double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net) {
   if (net)
     for (const Op& o : net->ops) f += o.flops_per_clip;
   return f;
+}
+
+extern "C" int ivf_i3d_num_conv_ops(const ivf_i3d_t* net) {
+  int n = 0;
+  if (net)
+    for (const Op& o : net->ops) n += (o.type == Op::CONV);
+  return n;
+}
+
+extern "C" int ivf_i3d_get_tuning(const ivf_i3d_t* net, int* v) {
+  IVF_CHECK_ARG(net && v, "i3d_get_tuning: null pointer");
+  int i = 0;
+  for (const Op& o : net->ops)
+    if (o.type == Op::CONV) { v[i++] = o.var_fwd; v[i++] = o.var_bwd; }
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_set_tuning(ivf_i3d_t* net, const int* v) {
+  IVF_CHECK_ARG(net && v, "i3d_set_tuning: null pointer");
+  int i = 0;
+  for (Op& o : net->ops)
+    if (o.type == Op::CONV) { o.var_fwd = v[i++]; o.var_bwd = v[i++]; }
+  return IVF_OK;
+}
+
+extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(reps >= 1, "i3d_autotune: reps >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  IVF_CHECK_HIP(hipEventCreate(&e0));
+  IVF_CHECK_HIP(hipEventCreate(&e1));
+  int rc = IVF_OK;
+  for (Op& o : net->ops) {
+    if (o.type != Op::CONV) continue;
+    const ConvLayer& L = net->convs[o.conv];
+    for (int dir = 0; dir < 2 && rc == IVF_OK; ++dir) {
+      ivf_conv3d_desc d;
+      int ids[32];
+      int* slot = dir == 0 ? &o.var_fwd : &o.var_bwd;
+      *slot = IVF_CONV_AUTO;
+      if (dir == 0) fill_conv_fwd(net, o, b, &d); else fill_conv_bwd(net, o, b, &d);
+      int nv = ivf_conv3d_variants(&d, ids, 32);
+      float best = 1e30f;
+      int best_id = IVF_CONV_AUTO;
+      for (int k = 0; k < nv; ++k) {
+        d.variant = ids[k];
+        auto run = [&]() {
+          return dir == 0 ? ivf_conv3d(&d, net->act(o.src), net->warena + L.wf_off, net->warena + L.scale_off,
+                                       net->warena + L.shift_off, nullptr, net->act(o.dst), s)
+                          : ivf_conv3d(&d, net->grad(o.dst), net->warena + L.wb_off, nullptr, nullptr,
+                                       o.bwd_mask ? net->act(o.src) : nullptr, net->grad(o.src), s);
+        };
+        if (run() != IVF_OK) continue;          // variant not applicable to this shape
+        (void)hipEventRecord(e0, s);
+        for (int r = 0; r < reps; ++r) (void)run();
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = IVF_ERR_HIP; set_error("autotune: sync failed"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; best_id = ids[k]; }
+      }
+      *slot = best_id;
+    }
+    if (rc != IVF_OK) break;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }

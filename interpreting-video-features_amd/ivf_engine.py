@@ -17,6 +17,8 @@ import ivf_lib as L
 
 # arithmetic of the Unit3D convolutions unless a caller overrides it (see include/ivf_hip.h)
 DEFAULT_MATH = os.environ.get("IVF_MATH", "fp32")
+# per-layer kernel autotuning when weights are first loaded (IVF_AUTOTUNE=0: built-in heuristic)
+AUTOTUNE = os.environ.get("IVF_AUTOTUNE", "1") != "0"
 
 
 def _arena(nbytes, device):
@@ -57,6 +59,7 @@ class I3DEngine:
             self._weights = _arena(L.lib().ivf_i3d_weights_bytes(self._h), self.device)
             self._ws = _arena(L.lib().ivf_i3d_workspace_bytes(self._h), self.device)
         L.check(L.lib().ivf_i3d_bind(self._h, L.ptr(self._weights), L.ptr(self._ws)))
+        self._tuned = False
         self.unit_names = []
         for i in range(L.lib().ivf_i3d_num_convs(self._h)):
             name = ctypes.create_string_buffer(64)
@@ -100,6 +103,31 @@ class I3DEngine:
                     L.check(L.lib().ivf_i3d_load_conv(self._h, i, L.ptr(w), L.ptr(g), L.ptr(b), L.ptr(m),
                                                       L.ptr(v), None, bn_eps, L.stream()))
             torch.cuda.current_stream().synchronize()   # sources may be freed after this
+        if AUTOTUNE and not self._tuned:
+            self.autotune()
+
+    # -------------------------------------------------------------- kernel selection
+    def autotune(self, reps=3):
+        """Time every kernel variant of every convolution at the plan's batch size and keep the
+        fastest per layer and direction.  Results: see get_tuning / set_tuning."""
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_i3d_autotune(self._h, self.max_batch, int(reps), L.stream()))
+            torch.cuda.current_stream().synchronize()
+        self._tuned = True
+
+    def get_tuning(self):
+        n = 2 * L.lib().ivf_i3d_num_conv_ops(self._h)
+        arr = (c_int * n)()
+        L.check(L.lib().ivf_i3d_get_tuning(self._h, arr))
+        return list(arr)
+
+    def set_tuning(self, variants):
+        n = 2 * L.lib().ivf_i3d_num_conv_ops(self._h)
+        if len(variants) != n:
+            raise L.IvfError(f"tuning vector must have {n} entries")
+        arr = (c_int * n)(*[int(v) for v in variants])
+        L.check(L.lib().ivf_i3d_set_tuning(self._h, arr))
+        self._tuned = True
 
     # -------------------------------------------------------------- helpers
     def _clip(self, x):

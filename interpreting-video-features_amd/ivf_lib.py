@@ -27,7 +27,7 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "Ti", "Hi", "Wi", "Cin", "in_ld", "in_coff", "To", "Ho", "Wo", "Cout", "out_ld",
         "out_coff", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "relu", "accumulate",
-        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math")]
+        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math", "variant")]
 
 
 class BwdGeom(Structure):
@@ -99,6 +99,11 @@ _SIGS = {
     "ivf_i3d_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
     "ivf_i3d_gradcam": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "ivf_i3d_conv_flops_per_clip": (ctypes.c_double, [_P]),
+    "ivf_conv3d_variants": (c_int, [POINTER(ConvDesc), POINTER(c_int), _I]),
+    "ivf_i3d_num_conv_ops": (c_int, [_P]),
+    "ivf_i3d_autotune": (c_int, [_P, _I, _I, _P]),
+    "ivf_i3d_get_tuning": (c_int, [_P, POINTER(c_int)]),
+    "ivf_i3d_set_tuning": (c_int, [_P, POINTER(c_int)]),
     "ivf_profile_enable": (c_int, [_I, _I]),
     "ivf_profile_disable": (c_int, []),
     "ivf_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),
