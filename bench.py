@@ -26,9 +26,25 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-VARIANT_NAMES = ("conv3d_igemm_kernel<128,128,2,2>", "conv3d_igemm_kernel<128,64,4,1>",
-                 "conv3d_igemm_kernel<128,32,4,1>")
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+PEAK_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+             "bf16x3": "bf16 dense MFMA (v_mfma_f32_32x32x16_bf16); every algorithmic FLOP costs 3 MFMA FLOPs "
+                       "in the split-bf16 mode, so the fp32-equivalent ceiling is 833 TFLOP/s"}
+_HALO = ["4,192,32,96,1", "4,128,64,64,1", "4,128,32,64,1", "4,96,32,96,1", "4,64,32,64,1", "4,64,64,64,2",
+         "4,32,32,32,1", "4,32,64,32,2", "2,192,32,96,1", "2,128,32,64,1", "2,96,32,96,1", "2,64,32,64,1",
+         "2,32,32,32,1", "2,64,64,64,2", "2,128,64,64,1", "4,64,32,64,2", "4,96,32,96,2", "4,32,32,32,2"]
+_IGEMM = ["128,128,2,2", "128,64,4,1", "128,32,4,1"]
+NCLASS = 48
+
+
+def variant_name(v):
+    """kernel template instance behind a profiler class id (include/ivf_hip.h)"""
+    if v >= 16:
+        return f"conv3d_halo_kernel<{_HALO[v - 16]}>"
+    if v >= 4:
+        return f"conv3d_igemm_bf16x3_kernel<{_IGEMM[v - 4]}>"
+    return f"conv3d_igemm_kernel<{_IGEMM[v - 1]}>"
 
 
 def host_cores():
@@ -98,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (reference batch_size=16)")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (searched together)")
     ap.add_argument("--iters", type=int, default=300, help="Adam iterations per search (reference N=300)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +148,13 @@ def main():
     T, B = args.frames, args.batch
     eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=B, softmax=True,
                                stride_mod_layers="" if T == 16 else "none", device=dev, math=args.math)
-    eng.load_state_dict(R.i3d_state_dict(num_classes=174))
+    eng.load_state_dict(R.i3d_state_dict(num_classes=174), autotune=(rank == 0))
+    if world > 1:
+        # every rank must run the SAME kernel variant per layer (bit-identical per-clip results):
+        # rank 0 tunes, one small broadcast installs its choice everywhere
+        tune = torch.tensor(eng.get_tuning(), dtype=torch.int32, device=dev)
+        dist.broadcast(tune, src=0)
+        eng.set_tuning(tune.cpu().tolist())
     searcher = ivf_search.MaskSearch(eng, lam1, lam2, args.iters, "freeze", grad_cam_type="guessed",
                                      do_gradcam=True)
     # synthetic clips, resident in HBM before the timed region; shard: clip_id % world == rank
@@ -169,38 +191,43 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    ms = (ctypes.c_double * 3)()
-    launches = (ctypes.c_longlong * 3)()
-    flops = (ctypes.c_double * 3)()
+    ms = (ctypes.c_double * NCLASS)()
+    launches = (ctypes.c_longlong * NCLASS)()
+    flops = (ctypes.c_double * NCLASS)()
     L.check(L.lib().ivf_profile_collect(ms, launches, flops))
     L.check(L.lib().ivf_profile_disable())
 
     if rank == 0:
         clips = world * B * args.steps
         value = clips / elapsed
-        dom = int(np.argmax([ms[v] for v in range(3)]))
+        math = eng.math
+        peak = PEAK_TFLOPS[math]
+        dom = int(np.argmax([ms[v] for v in range(NCLASS)]))
         roofline = None
         if launches[dom] > 0:
             avg_ms = ms[dom] / launches[dom]
             achieved = (flops[dom] / launches[dom]) / (avg_ms * 1e-3) / 1e12
-            tot_ms = sum(ms[v] for v in range(3))
-            tot_fl = sum(flops[v] for v in range(3))
+            tot_ms = sum(ms[v] for v in range(NCLASS))
+            tot_fl = sum(flops[v] for v in range(NCLASS))
+            shares = {variant_name(v): round(ms[v] / tot_ms, 3) for v in range(NCLASS) if launches[v] > 0}
             roofline = {
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": VARIANT_NAMES[dom], "avg_launch_ms": round(avg_ms, 4),
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": variant_name(dom), "avg_launch_ms": round(avg_ms, 4),
                 "sampled_launches": int(launches[dom]),
                 "algorithmic_gflop_per_launch": round(flops[dom] / launches[dom] / 1e9, 3),
-                "all_conv_variants": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                      "share_of_sampled_conv_time": {VARIANT_NAMES[v]: round(ms[v] / tot_ms, 3)
-                                                                     for v in range(3)}},
-                "peak_dtype": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                "mfma_passes_per_algorithmic_flop": 3 if math == "bf16x3" else 1,
+                "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                     "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                                     "share_of_sampled_conv_time": shares},
+                "peak_dtype": PEAK_NOTE[math],
             }
         out = {
             "metric": "clips/sec full mask-search (I3D, 16f, 300 iters)",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if eng.math == "fp32" else "bf16x3 (split-bf16 MFMA, f32 accumulate, f32 storage)",
             "data": "synthetic",
             "config": {"workload": f"I3D perturbation mask search, {args.iters} iters, synthetic clips "
                                    f"[{B},3,{T},224,224] per GPU per step (BASELINE configs[1]); init_mask + "

@@ -346,10 +346,12 @@ double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net);
 
 /* ------------------------------------------------------------------ measurement */
 
-/* HIP-event timing of the implicit-GEMM convolution launches on their own stream,
- * sampled on every `every`-th iteration of ivf_*_search (bench.py's roofline leg).
- * collect: per tile variant v (0: 128x128, 1: 128x64, 2: 128x32) summed kernel
- * milliseconds, launch count and algorithmic FLOPs of the sampled launches. */
+/* HIP-event timing of the convolution launches on their own stream, sampled on every
+ * `every`-th iteration of ivf_*_search (bench.py's roofline leg).  collect: arrays of
+ * IVF_PROFILE_CLASSES entries indexed by kernel variant id (IVF_CONV_IGEMM_BASE + tile for
+ * fp32, +3 for split-bf16; IVF_CONV_HALO_BASE + i): summed kernel milliseconds, launch count
+ * and algorithmic FLOPs of the sampled launches. */
+#define IVF_PROFILE_CLASSES 48
 int ivf_profile_enable(int every, int max_launches);
 int ivf_profile_disable(void);
 int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);

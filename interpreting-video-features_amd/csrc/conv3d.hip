@@ -437,7 +437,7 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
-  const bool timed = prof_begin(s, BN == 128 ? 0 : (BN == 64 ? 1 : 2));
+  const bool timed = prof_begin(s, IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0));
   if (math == 0)
     hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
   else

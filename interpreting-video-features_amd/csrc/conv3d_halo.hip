@@ -404,11 +404,14 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
 }
 
 template <int TT, int BN, int WROWS, int WCOLS, int KS = 1>
-static int launch_halo(ConvKArgs& a, hipStream_t s) {
+static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int NT = (TT * 64 / WROWS) * (BN / WCOLS) * KS * 64;
   const int HR = (TT + a.kT - 1) * (TH + a.kH - 1) * (TW + a.kW - 1);
   const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
-  static_assert(KS == 1 || (size_t)TT * 64 * BN * 4 <= 64 * 1024, "reduction buffer must fit the halo area");
+  if (KS == 2 && (size_t)TT * 64 * BN * 4 > (size_t)2 * HR * ROWB) {
+    set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
+    return IVF_ERR_UNSUPPORTED;
+  }
   if (shm > 160 * 1024) {
     set_error("conv3d_halo: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;
@@ -423,7 +426,7 @@ static int launch_halo(ConvKArgs& a, hipStream_t s) {
   a.ntiles = cdiv(a.Cout, BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
-  const bool timed = prof_begin(s, BN >= 128 ? 0 : (BN >= 64 ? 1 : 2));
+  const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
   hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
@@ -443,25 +446,29 @@ int conv_halo_supported(const ConvKArgs& a) {
 //  4: 4  64  32 x 64  1      5: 4  64  64 x 64  2     6: 4  32  32 x 32  1     7: 4  32  64 x 32  2
 //  8: 2 192  32 x 96  1      9: 2 128  32 x 64  1    10: 2  96  32 x 96  1    11: 2  64  32 x 64  1
 // 12: 2  32  32 x 32  1     13: 2  64  64 x 64  2    14: 2 128  64 x 64  1
-int conv_halo_num_variants() { return 15; }
+// 15: 4  64  32 x 64  2     16: 4  96  32 x 96  2    17: 4  32  32 x 32  2
+int conv_halo_num_variants() { return 18; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
-    case 0: return launch_halo<4, 192, 32, 96>(a, s);
-    case 1: return launch_halo<4, 128, 64, 64>(a, s);
-    case 2: return launch_halo<4, 128, 32, 64>(a, s);
-    case 3: return launch_halo<4, 96, 32, 96>(a, s);
-    case 4: return launch_halo<4, 64, 32, 64>(a, s);
-    case 5: return launch_halo<4, 64, 64, 64, 2>(a, s);
-    case 6: return launch_halo<4, 32, 32, 32>(a, s);
-    case 7: return launch_halo<4, 32, 64, 32, 2>(a, s);
-    case 8: return launch_halo<2, 192, 32, 96>(a, s);
-    case 9: return launch_halo<2, 128, 32, 64>(a, s);
-    case 10: return launch_halo<2, 96, 32, 96>(a, s);
-    case 11: return launch_halo<2, 64, 32, 64>(a, s);
-    case 12: return launch_halo<2, 32, 32, 32>(a, s);
-    case 13: return launch_halo<2, 64, 64, 64, 2>(a, s);
-    case 14: return launch_halo<2, 128, 64, 64>(a, s);
+    case 0: return launch_halo<4, 192, 32, 96>(a, 0, s);
+    case 1: return launch_halo<4, 128, 64, 64>(a, 1, s);
+    case 2: return launch_halo<4, 128, 32, 64>(a, 2, s);
+    case 3: return launch_halo<4, 96, 32, 96>(a, 3, s);
+    case 4: return launch_halo<4, 64, 32, 64>(a, 4, s);
+    case 5: return launch_halo<4, 64, 64, 64, 2>(a, 5, s);
+    case 6: return launch_halo<4, 32, 32, 32>(a, 6, s);
+    case 7: return launch_halo<4, 32, 64, 32, 2>(a, 7, s);
+    case 8: return launch_halo<2, 192, 32, 96>(a, 8, s);
+    case 9: return launch_halo<2, 128, 32, 64>(a, 9, s);
+    case 10: return launch_halo<2, 96, 32, 96>(a, 10, s);
+    case 11: return launch_halo<2, 64, 32, 64>(a, 11, s);
+    case 12: return launch_halo<2, 32, 32, 32>(a, 12, s);
+    case 13: return launch_halo<2, 64, 64, 64, 2>(a, 13, s);
+    case 14: return launch_halo<2, 128, 64, 64>(a, 14, s);
+    case 15: return launch_halo<4, 64, 32, 64, 2>(a, 15, s);
+    case 16: return launch_halo<4, 96, 32, 96, 2>(a, 16, s);
+    case 17: return launch_halo<4, 32, 32, 32, 2>(a, 17, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

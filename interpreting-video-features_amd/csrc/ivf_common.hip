@@ -73,17 +73,18 @@ extern "C" int ivf_profile_disable(void) {
   return IVF_OK;
 }
 
-// Sums per tile variant v in [0,3): kernel_ms[v], launches[v], flops[v]; resets the sample.
-// Synchronises on the recorded events (call outside the timed region).
+// Sums per kernel variant id v in [0,IVF_PROFILE_CLASSES): kernel_ms[v], launches[v], flops[v];
+// resets the sample.  Synchronises on the recorded events (call outside the timed region).
 extern "C" int ivf_profile_collect(double* kernel_ms, long long* launches, double* flops) {
   IVF_CHECK_ARG(kernel_ms && launches && flops, "profile_collect: null pointer");
   ivf::Prof& p = ivf::g_prof;
-  for (int v = 0; v < 3; ++v) { kernel_ms[v] = 0.0; launches[v] = 0; flops[v] = 0.0; }
+  for (int v = 0; v < IVF_PROFILE_CLASSES; ++v) { kernel_ms[v] = 0.0; launches[v] = 0; flops[v] = 0.0; }
   for (size_t i = 0; i < p.used; ++i) {
     IVF_CHECK_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
     float ms = 0.f;
     IVF_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
     int v = p.variant[i];
+    if (v < 0 || v >= IVF_PROFILE_CLASSES) continue;
     kernel_ms[v] += ms;
     launches[v] += 1;
     flops[v] += p.flops[i];

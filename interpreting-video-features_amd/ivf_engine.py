@@ -16,7 +16,7 @@ import ivf_lib as L
 
 
 # arithmetic of the Unit3D convolutions unless a caller overrides it (see include/ivf_hip.h)
-DEFAULT_MATH = os.environ.get("IVF_MATH", "fp32")
+DEFAULT_MATH = os.environ.get("IVF_MATH", "bf16x3")
 # per-layer kernel autotuning when weights are first loaded (IVF_AUTOTUNE=0: built-in heuristic)
 AUTOTUNE = os.environ.get("IVF_AUTOTUNE", "1") != "0"
 
@@ -77,7 +77,7 @@ class I3DEngine:
         return self._ws.numel()
 
     # -------------------------------------------------------------- weights
-    def load_state_dict(self, sd, bn_eps=1e-3):
+    def load_state_dict(self, sd, bn_eps=1e-3, autotune=None):
         """sd: reference key scheme, optional 'module.' prefix."""
         def get(key):
             for k in (key, "module." + key):
@@ -103,7 +103,7 @@ class I3DEngine:
                     L.check(L.lib().ivf_i3d_load_conv(self._h, i, L.ptr(w), L.ptr(g), L.ptr(b), L.ptr(m),
                                                       L.ptr(v), None, bn_eps, L.stream()))
             torch.cuda.current_stream().synchronize()   # sources may be freed after this
-        if AUTOTUNE and not self._tuned:
+        if (AUTOTUNE if autotune is None else autotune) and not self._tuned:
             self.autotune()
 
     # -------------------------------------------------------------- kernel selection
