@@ -134,7 +134,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
 // (backward) once per window that covers it -- up to 27x through L1/L2.  The tiled forms
 // stage the needed region of one 32-channel slab in LDS once (coalesced 128-byte rows) and
 // run the same window scan / gather against LDS, so global traffic is ~1x the tensors.
-constexpr int POOL_SLAB = 32;       // channels per workgroup
+constexpr int POOL_SLAB = 16;       // channels per workgroup
 constexpr int POOL_ROW = POOL_SLAB + 4;   // floats per LDS row (pad: conflict-free 16-byte reads)
 
 struct PoolTile {
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
   const int c0 = slab * POOL_SLAB;
   const int nreg = t.rT * t.rH * t.rW;
   // stage: 8 float4 per position, zero fill outside the tensor (zero padding) and beyond C
-  for (int i = threadIdx.x; i < nreg * 8; i += blockDim.x) {
-    int g = i & 7, r = i >> 3;
+  for (int i = threadIdx.x; i < nreg * (POOL_SLAB / 4); i += blockDim.x) {
+    int g = i % (POOL_SLAB / 4), r = i / (POOL_SLAB / 4);
     int rw = r % t.rW;
     int r2 = r / t.rW;
     int rh = r2 % t.rH;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
   }
   __syncthreads();
   const int nout = t.tT * t.tH * t.tW;
-  for (int i = threadIdx.x; i < nout * 8; i += blockDim.x) {
-    int g = i & 7, o = i >> 3;
+  for (int i = threadIdx.x; i < nout * (POOL_SLAB / 4); i += blockDim.x) {
+    int g = i % (POOL_SLAB / 4), o = i / (POOL_SLAB / 4);
     int ow = o % t.tW;
     int o2 = o / t.tW;
     int oh = o2 % t.tH;
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __r
   const int c0 = slab * POOL_SLAB;
   const int nreg = t.rT * t.rH * t.rW;
   unsigned char* si = reinterpret_cast<unsigned char*>(sm + (size_t)nreg * POOL_ROW);   // [nreg][POOL_SLAB]
-  for (int i = threadIdx.x; i < nreg * 8; i += blockDim.x) {
-    int g = i & 7, r = i >> 3;
+  for (int i = threadIdx.x; i < nreg * (POOL_SLAB / 4); i += blockDim.x) {
+    int g = i % (POOL_SLAB / 4), r = i / (POOL_SLAB / 4);
     int rw = r % t.rW;
     int r2 = r / t.rW;
     int rh = r2 % t.rH;
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __r
   }
   __syncthreads();
   const int nin = t.tT * t.tH * t.tW;
-  for (int i = threadIdx.x; i < nin * 8; i += blockDim.x) {
-    int g = i & 7, p = i >> 3;
+  for (int i = threadIdx.x; i < nin * (POOL_SLAB / 4); i += blockDim.x) {
+    int g = i % (POOL_SLAB / 4), p = i / (POOL_SLAB / 4);
     int pw = p % t.tW;
     int p2 = p / t.tW;
     int ph = p2 % t.tH;
@@ -588,9 +588,10 @@ extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float
   PoolTile t;
   pool_fwd_tile(a, &t);
   size_t shm = (size_t)t.rT * t.rH * t.rW * POOL_ROW * sizeof(float);
-  // measured on MI355X: L1/L2 already serve the forward window re-reads well; the tiled form
-  // only wins when forced (kept for A/B runs: IVF_POOL_TILED_FWD=1)
-  static const bool tiled_fwd = getenv("IVF_POOL_TILED_FWD") != nullptr;
+  // measured on MI355X (16-channel slabs): the tiled form wins 1.4x for the stride-1 3x3x3
+  // Inception pools (the direct kernel saturates L2 with its 27x re-reads) and loses for the
+  // strided pools, whose windows barely overlap
+  const bool tiled_fwd = a.sT == 1 && a.sH == 1 && a.sW == 1;
   if (!direct && tiled_fwd && shm <= 64 * 1024) {
     long blocks = (long)a.B * t.nT * t.nH * t.nW * t.slabs;
     hipLaunchKernelGGL(maxpool_fwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), shm, (hipStream_t)stream, x, y,
@@ -615,9 +616,8 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
   PoolTile t;
   pool_bwd_tile(a, &t);
   size_t shm = (size_t)t.rT * t.rH * t.rW * (POOL_ROW * sizeof(float) + POOL_SLAB);
-  // measured: the tiled gather wins for strided pools (1.3-1.6x), loses slightly at stride 1
-  const bool strided = a.sT > 1 || a.sH > 1 || a.sW > 1;
-  if (!direct && strided && shm <= 80 * 1024) {
+  // measured (16-channel slabs): the tiled gather wins 1.3-1.6x for every pool of the net
+  if (!direct && shm <= 80 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
       IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maxpool_bwd_tiled_kernel),
