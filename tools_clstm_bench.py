@@ -1,0 +1,15 @@
+"""ConvLSTM (BASELINE configs[3]) mask-search throughput: clips/s for N=100 iterations."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
+import numpy as np, torch
+import ivf_engine, ivf_recipe as R, ivf_search
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+eng = ivf_engine.CLSTMEngine(6, (C, 32, 120, 160), max_batch=B, hidden=4, layers=2, kernel=5, stride=2, softmax=True)
+eng.load_state_dict(R.clstm_state_dict(channels=C, tag=f'clstm{C}'))
+x = torch.stack([torch.from_numpy(R.clip(i % 8, C, 32, 120, 160) / 255.0).float() for i in range(B)]).cuda()
+s = ivf_search.MaskSearch(eng, 0.02, 0.04, 100, "freeze", do_gradcam=False)
+s.run(x, [0] * B); torch.cuda.synchronize()
+t0 = time.perf_counter(); s.run(x, [0] * B); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"CLSTM_4 C={C} B={B}: {B/dt:.1f} clips/s (100-iteration search, {dt*1e3/100:.2f} ms per iteration of {B} clips)")
