@@ -25,16 +25,14 @@ constexpr int MAXK = 7;
 
 // Gx[b,t,g*hid+j,yo,xo] = bias[g][j] + sum_{c,ky,kx} Wx[g][j][c][ky][kx] * x[b,c,t,yo*s-p+ky,xo*s-p+kx]
 // x addressed by generic strides (elements): b*sB + c*sC + t*sT + y*W + x.
+// Weight tables are pre-transposed to [c][ky][kx][16 gate-channels] (and [ky][kx][16][4] for the
+// backward kernels): the index is wave-uniform, so the compiler fetches the 16 weights of a
+// tap with one scalar load and the FMAs take them as SGPR operands -- no LDS traffic at all.
 __global__ __launch_bounds__(256) void clstm_xconv_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
     float* __restrict__ gx, int B, int T, int Cin, int H, int W, long sB, long sC, long sT, int hid, int k,
     int stride, int Ho, int Wo) {
-  extern __shared__ float sw[];  // [4*hid][Cin][k][k] + [4*hid] bias
   const int G = 4 * hid;
-  const int nw = G * Cin * k * k;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
-  for (int i = threadIdx.x; i < G; i += blockDim.x) sw[nw + i] = bias ? bias[i] : 0.f;
-  __syncthreads();
   const int pad = (k - 1) / 2;
   const long total = (long)B * T * Ho * Wo;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -44,20 +42,17 @@ __global__ __launch_bounds__(256) void clstm_xconv_fwd_kernel(
     int b = i / ((long)Wo * Ho * T);
     float acc[16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = (o < G) ? sw[nw + o] : 0.f;
+    for (int o = 0; o < 16; ++o) acc[o] = (bias && o < G) ? bias[o] : 0.f;
     for (int c = 0; c < Cin; ++c) {
       const float* xp = x + b * sB + c * sC + t * sT;
       for (int ky = 0; ky < k; ++ky) {
         int y = yo * stride - pad + ky;
-        if ((unsigned)y >= (unsigned)H) continue;
         for (int kx = 0; kx < k; ++kx) {
           int xx = xo * stride - pad + kx;
-          if ((unsigned)xx >= (unsigned)W) continue;
-          float v = xp[(long)y * W + xx];
-          const float* wp = sw + (c * k + ky) * k + kx;
+          float v = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? xp[(long)y * W + xx] : 0.f;
+          const float* wp = wT + ((c * k + ky) * k + kx) * 16;
 #pragma unroll
-          for (int o = 0; o < 16; ++o)
-            if (o < G) acc[o] += wp[o * Cin * k * k] * v;
+          for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
         }
       }
     }
@@ -73,13 +68,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // One cell step for all clips: gates = Gx[t] + Wh * h[t-1]; state update; saves
 // S[b,t,{i,f,g,o,c},j,y,x] and H[b,t,j,y,x].
 __global__ __launch_bounds__(256) void clstm_step_fwd_kernel(
-    const float* __restrict__ gx, const float* __restrict__ wh, float* __restrict__ S, float* __restrict__ Hs,
+    const float* __restrict__ gx, const float* __restrict__ whT, float* __restrict__ S, float* __restrict__ Hs,
     int B, int T, int t, int hid, int k, int Ho, int Wo) {
-  extern __shared__ float sw[];  // [4*hid][hid][k][k]
   const int G = 4 * hid;
-  const int nw = G * hid * k * k;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = wh[i];
-  __syncthreads();
   const int pad = (k - 1) / 2;
   const long plane = (long)Ho * Wo;
   const long total = (long)B * plane;
@@ -96,15 +87,13 @@ __global__ __launch_bounds__(256) void clstm_step_fwd_kernel(
       for (int c = 0; c < hid; ++c)
         for (int ky = 0; ky < k; ++ky) {
           int y = yo - pad + ky;
-          if ((unsigned)y >= (unsigned)Ho) continue;
           for (int kx = 0; kx < k; ++kx) {
             int xx = xo - pad + kx;
-            if ((unsigned)xx >= (unsigned)Wo) continue;
-            float v = hp[(long)c * plane + (long)y * Wo + xx];
-            const float* wp = sw + (c * k + ky) * k + kx;
+            float v = ((unsigned)y < (unsigned)Ho && (unsigned)xx < (unsigned)Wo)
+                          ? hp[(long)c * plane + (long)y * Wo + xx] : 0.f;
+            const float* wp = whT + ((c * k + ky) * k + kx) * 16;
 #pragma unroll
-            for (int o = 0; o < 16; ++o)
-              if (o < G) acc[o] += wp[o * hid * k * k] * v;
+            for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
           }
         }
     }
@@ -178,13 +167,9 @@ __global__ void clstm_unpool_bwd_kernel(const float* __restrict__ dX, const unsi
 // dh = dHpool[t] + Wh^T (x) dG[t+1];  do = dh*tanh(c); dc = dh*o*(1-tanh^2 c) + dC;
 // di = dc*g; df = dc*c_prev; dg = dc*i; dC <- dc*f;  dG = gate derivatives.
 __global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
-    const float* __restrict__ dHpool, const float* __restrict__ wh, const float* __restrict__ S,
+    const float* __restrict__ dHpool, const float* __restrict__ whB, const float* __restrict__ S,
     float* __restrict__ dG, float* __restrict__ dC, int B, int T, int t, int hid, int k, int Ho, int Wo) {
-  extern __shared__ float sw[];
   const int G = 4 * hid;
-  const int nw = G * hid * k * k;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = wh[i];
-  __syncthreads();
   const int pad = (k - 1) / 2;
   const long plane = (long)Ho * Wo;
   const long total = (long)B * plane;
@@ -198,16 +183,15 @@ __global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
       const float* gp = dG + (((long)b * T + (t + 1)) * G) * plane;
       for (int ky = 0; ky < k; ++ky) {
         int yy = y - ky + pad;
-        if ((unsigned)yy >= (unsigned)Ho) continue;
         for (int kx = 0; kx < k; ++kx) {
           int xx = x - kx + pad;
-          if ((unsigned)xx >= (unsigned)Wo) continue;
-          for (int o = 0; o < G; ++o) {
-            float g = gp[(long)o * plane + (long)yy * Wo + xx];
-            const float* wp = sw + (o * hid * k + ky) * k + kx;
+          const bool ok = (unsigned)yy < (unsigned)Ho && (unsigned)xx < (unsigned)Wo;
+          const float* wp = whB + (ky * k + kx) * 64;     // [o][j], j padded to 4
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < hid) dh[j] += wp[j * k * k] * g;
+          for (int o = 0; o < 16; ++o) {
+            float g = (ok && o < G) ? gp[(long)o * plane + (long)yy * Wo + xx] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dh[j] += wp[o * 4 + j] * g;
           }
         }
       }
@@ -235,13 +219,9 @@ __global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
 
 // dx[b,c,t,y,x] = sum_{o,ky,kx} Wx[o][c][ky][kx] * dG[b,t,o,(y+p-ky)/s,(x+p-kx)/s]  (exact divisions only)
 __global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
-    const float* __restrict__ dG, const float* __restrict__ w, float* __restrict__ dx, int B, int T, int Cin,
+    const float* __restrict__ dG, const float* __restrict__ wB, float* __restrict__ dx, int B, int T, int Cin,
     int H, int W, long sB, long sC, long sT, int hid, int k, int stride, int Ho, int Wo) {
-  extern __shared__ float sw[];
   const int G = 4 * hid;
-  const int nw = G * Cin * k * k;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
-  __syncthreads();
   const int pad = (k - 1) / 2;
   const long plane = (long)Ho * Wo;
   const long total = (long)B * T * H * W;
@@ -262,16 +242,34 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
         if (nx < 0 || nx % stride) continue;
         int xo = nx / stride;
         if (xo >= Wo) continue;
-        for (int o = 0; o < G; ++o) {
-          float g = gp[(long)o * plane + (long)yo * Wo + xo];
-          const float* wp = sw + (o * Cin * k + ky) * k + kx;
+        const float* wp = wB + (ky * k + kx) * 64;     // [o][c], c padded to 4
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c < Cin) acc[c] += wp[c * k * k] * g;
+        for (int o = 0; o < 16; ++o) {
+          float g = (o < G) ? gp[(long)o * plane + (long)yo * Wo + xo] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += wp[o * 4 + c] * g;
         }
       }
     }
     for (int c = 0; c < Cin; ++c) dx[b * sB + c * sC + t * sT + (long)y * W + x] = acc[c];
+  }
+}
+
+// raw [G][cin][k][k] -> fwd table [cin][k][k][16] and bwd table [k][k][16][4] (zero padded)
+__global__ void clstm_weight_tables_kernel(const float* __restrict__ w, float* __restrict__ wT,
+                                           float* __restrict__ wB, int G, int cin, int k) {
+  int nT = cin * k * k * 16, nB = k * k * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nT + nB; i += gridDim.x * blockDim.x) {
+    if (i < nT) {
+      int o = i & 15, r = i >> 4;
+      int kx = r % k, ky = (r / k) % k, c = r / (k * k);
+      wT[i] = o < G ? w[((o * cin + c) * k + ky) * k + kx] : 0.f;
+    } else {
+      int q = i - nT;
+      int c = q & 3, o = (q >> 2) & 15, r = q >> 6;
+      int kx = r % k, ky = r / k;
+      wB[q] = (o < G && c < cin) ? w[((o * cin + c) * k + ky) * k + kx] : 0.f;
+    }
   }
 }
 
@@ -329,7 +327,8 @@ static inline int grid_for(long total, int block = 256, int cap = 4096) {
 
 struct LayerPlan {
   int cin, Hin, Win, Ho, Wo, Hp, Wp;
-  size_t wx_off, bx_off, wh_off;                    // floats in weights arena
+  size_t wx_off, bx_off, wh_off;                    // floats in weights arena (raw reference layout)
+  size_t wxT_off, wxB_off, whT_off, whB_off;        // transposed tables for the scalar-load kernels
   size_t gx_off, S_off, H_off, X_off, dG_off, dHp_off, dC_off, dX_off;  // floats in workspace
   size_t arg_off;                                   // bytes
 };
@@ -389,6 +388,10 @@ extern "C" int ivf_clstm_create(const ivf_clstm_config* c, ivf_clstm_t** out) {
     p.wx_off = takew((size_t)G * cin * k * k);
     p.bx_off = takew(G);
     p.wh_off = takew((size_t)G * hid * k * k);
+    p.wxT_off = takew((size_t)cin * k * k * 16);
+    p.wxB_off = takew((size_t)k * k * 64);
+    p.whT_off = takew((size_t)hid * k * k * 16);
+    p.whB_off = takew((size_t)k * k * 64);
     size_t plane = (size_t)p.Ho * p.Wo;
     p.gx_off = takef(B * T * G * plane);
     p.S_off = takef(B * T * 5 * hid * plane);
@@ -464,6 +467,12 @@ extern "C" int ivf_clstm_load_cell(ivf_clstm_t* n, int layer, const float* wxi, 
     IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.bx_off + g * hid, bx[g], (size_t)hid * 4, hipMemcpyDeviceToDevice, s));
     IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.wh_off + g * eh, wh[g], eh * 4, hipMemcpyDeviceToDevice, s));
   }
+  hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wx_off, n->wa + p.wxT_off,
+                     n->wa + p.wxB_off, 4 * hid, p.cin, k);
+  IVF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wh_off, n->wa + p.whT_off,
+                     n->wa + p.whB_off, 4 * hid, hid, k);
+  IVF_CHECK_LAUNCH();
   n->cell_loaded[layer] = true;
   return IVF_OK;
 }
@@ -499,7 +508,7 @@ static int clstm_ready(const ivf_clstm* n, int b) {
 // forward of the clip held at `x` (NCTHW); leaves activations in the workspace
 static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits, float* probs, hipStream_t s) {
   const ivf_clstm_config& c = n->cfg;
-  const int hid = c.hidden, k = c.kernel, G = 4 * hid, T = c.T;
+  const int hid = c.hidden, k = c.kernel, T = c.T;
   const float* sc = c.batch_norm ? n->wa + n->bn_scale_off : nullptr;
   const float* sh = c.batch_norm ? n->wa + n->bn_shift_off : nullptr;
   for (size_t i = 0; i < n->L.size(); ++i) {
@@ -514,15 +523,13 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
       in = n->wsf(q.X_off);
       sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
     }
-    size_t shm = ((size_t)G * p.cin * k * k + G) * 4;
-    hipLaunchKernelGGL(clstm_xconv_fwd_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo)), dim3(256), shm, s, in,
-                       n->wa + p.wx_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
+    hipLaunchKernelGGL(clstm_xconv_fwd_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo, 256, 16384)), dim3(256), 0, s, in,
+                       n->wa + p.wxT_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
                        hid, k, c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
-    size_t shm_h = (size_t)G * hid * k * k * 4;
     for (int t = 0; t < T; ++t) {
-      hipLaunchKernelGGL(clstm_step_fwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 1024)), dim3(256), shm_h,
-                         s, n->wsf(p.gx_off), n->wa + p.wh_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
+      hipLaunchKernelGGL(clstm_step_fwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
+                         s, n->wsf(p.gx_off), n->wa + p.whT_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
                          p.Ho, p.Wo);
       IVF_CHECK_LAUNCH();
     }
@@ -550,7 +557,7 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
 static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const float* dout, float* score, float* dx,
                               hipStream_t s) {
   const ivf_clstm_config& c = n->cfg;
-  const int hid = c.hidden, k = c.kernel, G = 4 * hid, T = c.T;
+  const int hid = c.hidden, k = c.kernel, T = c.T;
   const float* sc = c.batch_norm ? n->wa + n->bn_scale_off : nullptr;
   float* flat = n->at<float>(n->off_flat);
   float* dflat = n->at<float>(n->off_dflat);
@@ -569,10 +576,9 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
                        n->wsf(p.dX_off), n->at<unsigned char>(p.arg_off), sc, n->wsf(p.dHp_off), (long)b * T, hid,
                        p.Ho, p.Wo, p.Hp, p.Wp);
     IVF_CHECK_LAUNCH();
-    size_t shm_h = (size_t)G * hid * k * k * 4;
     for (int t = T - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(clstm_step_bwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 1024)), dim3(256), shm_h,
-                         s, n->wsf(p.dHp_off), n->wa + p.wh_off, n->wsf(p.S_off), n->wsf(p.dG_off),
+      hipLaunchKernelGGL(clstm_step_bwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
+                         s, n->wsf(p.dHp_off), n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off),
                          n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
       IVF_CHECK_LAUNCH();
     }
@@ -586,9 +592,8 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
       out = n->wsf(q.dX_off);
       sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
     }
-    size_t shm = (size_t)G * p.cin * k * k * 4;
-    hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win)), dim3(256), shm, s,
-                       n->wsf(p.dG_off), n->wa + p.wx_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
+    hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384)), dim3(256), 0, s,
+                       n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
                        c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
   }
