@@ -528,7 +528,7 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     IVF_CHECK_ARG(relu_mask == nullptr, "conv3d: relu_mask unsupported with depth-to-space");
     IVF_CHECK_ARG(d->bsT >= 1 && d->bsT <= 2 && d->bsH >= 1 && d->bsH <= 2 && d->bsW >= 1 && d->bsW <= 2,
                   "conv3d: block strides must be 1 or 2");
-    IVF_CHECK_ARG(d->Cout % 8 == 0, "conv3d: depth-to-space needs Cout = 8 * Cpad");
+    IVF_CHECK_ARG(d->Cout % 8 == 0 && d->Cout <= 32, "conv3d: depth-to-space needs Cout = 8 * Cpad <= 32");
     IVF_CHECK_ARG(d->dT > 0 && d->dH > 0 && d->dW > 0 && d->dC > 0 && d->dC <= d->Cout / 8,
                   "conv3d: bad depth-to-space dims");
     IVF_CHECK_ARG(d->out_coff + d->dC <= d->out_ld, "conv3d: d2s output window outside ld");

@@ -10,6 +10,8 @@
 // a tap only changes the LDS row offset of the A fragments.  Only the small weight tile
 // (BN x 32) streams per tap, double-buffered so its loads fly under the previous tap's MFMAs
 // (one barrier per tap).  Input bytes per MAC drop ~8x for 3x3x3.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace ivf {
@@ -308,17 +310,21 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
     // tap loop unrolled by PF so the register ring is statically indexed: at tap (slot u)
     // the LDS buffer tap&1 holds its weights; slot u is refilled with tap+PF, and slot u+1's
     // weights (tap+1, loaded PF-1 taps ago) move to the other LDS buffer after the MFMAs.
-    for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int tap = tap0 + u;   // step index within the chunk
-        if (tap < nsteps) {
-          if (tap + PF < nsteps && !(a.dbg & 8)) load_b(u, tap + PF, c0);
-          if (!(a.dbg & 32)) mma_tap(tap, tap & 1, nks);
-          if (tap + 1 < nsteps && !(a.dbg & 8)) store_b((u + 1) % PF, (tap + 1) & 1);
-          if (!(a.dbg & 16)) __syncthreads();
-        }
+    auto tap_body = [&](auto U, int tap0) {
+      constexpr int u = decltype(U)::value;
+      const int tap = tap0 + u;   // step index within the chunk
+      if (tap < nsteps) {
+        if (tap + PF < nsteps && !(a.dbg & 8)) load_b(u, tap + PF, c0);
+        if (!(a.dbg & 32)) mma_tap(tap, tap & 1, nks);
+        if (tap + 1 < nsteps && !(a.dbg & 8)) store_b((u + 1) % PF, (tap + 1) & 1);
+        if (!(a.dbg & 16)) __syncthreads();
       }
+    };
+    static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
+    for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
+      tap_body(std::integral_constant<int, 0>{}, tap0);
+      tap_body(std::integral_constant<int, 1>{}, tap0);
+      tap_body(std::integral_constant<int, 2>{}, tap0);
     }
   }
 

@@ -72,10 +72,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     // depth-to-space: n = ((pt*2+ph)*2+pw)*cpad + c with cpad == 4: the 4 channels of one
     // output pixel sit on 4 consecutive lanes; gather them with quad DPP moves and let the
     // c == 0 lane store one 16-byte vector.
+    // (Cout = 8 * cpad <= 32 here -- the host checks it -- so only the first 32-column tile of a
+    // wave can hold real columns; handling just j = 0 keeps this branch small enough to unroll.)
     const int cpad = a.Cout >> 3;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = col_base + j * 32 + li;
+    {
+      constexpr int j = 0;
+      const int n = col_base + li;
       const int par = n / cpad, c = n - par * cpad;
       const int pt = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
       const bool nvalid = n < a.Cout && pt < a.bsT && ph < a.bsH && pw < a.bsW;
