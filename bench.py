@@ -210,9 +210,21 @@ def main():
             tot_ms = sum(ms[v] for v in range(NCLASS))
             tot_fl = sum(flops[v] for v in range(NCLASS))
             shares = {variant_name(v): round(ms[v] / tot_ms, 3) for v in range(NCLASS) if launches[v] > 0}
+            # HBM bytes per launch of that kernel from the committed PMC passes (profiles/), if the
+            # same kernel variant was measured there at this batch size; else null
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                ent = pm["kernels"].get(variant_name(dom))
+                if ent and pm.get("batch") == B:
+                    traffic = ent["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes, FETCH doubled per the gfx950 rule)" if traffic else None,
                 "kernel": variant_name(dom), "avg_launch_ms": round(avg_ms, 4),
                 "sampled_launches": int(launches[dom]),
                 "algorithmic_gflop_per_launch": round(flops[dom] / launches[dom] / 1e9, 3),
