@@ -106,3 +106,40 @@ def test_find_masks_records(model, tmp_path, monkeypatch):
     m1 = drv.find_masks(loader1, model, {"batch_size": 1, "gradCamType": "guessed"}, 0.01, 0.02, 5, "central",
                         "freeze", classOI=None, doGradCam=False, runTempMask=True, verbose=False)
     assert torch.equal(m1[0], masks[1])
+
+
+def test_mask_module_edges(model):
+    """argument handling the reference has: unknown perturbation type, random init,
+    snap_values mutating the caller's mask, sub-mask lists on the device."""
+    import ivf_recipe as R
+    import mask
+    x = torch.from_numpy(R.uniform('t/edge/x', (1, 3, 16, 8, 8), 0, 255)).cuda()
+    m = torch.from_numpy(R.uniform('t/edge/m', (16,), 0, 1)).cuda()
+    with pytest.raises(UnboundLocalError):
+        mask.perturb_sequence(x, m, perturbation_type='blur')        # mask.py:57 returns an unset local
+    m2 = m.clone()
+    p = mask.perturb_sequence(x, m2, 'freeze', snap_values=True)
+    assert set(m2.unique().tolist()) <= {0.0, 1.0} and torch.equal(m2, (m > 0.5).float())   # mask.py:5-10
+    assert p.shape == x.shape
+    runs = mask.find_submasks_from_mask(torch.tensor([0, .2, .3, 0, 0, .5, 0, .1, .11, 0, 0, 0, 0, 0, .9, .9]).cuda())
+    assert runs == [[1, 2], [5], [8], [14, 15]]
+    torch.manual_seed(0)
+    r = mask.init_mask(x, None, 0, None if False else torch.zeros(1, 1).long(), mode="random")
+    assert r.requires_grad and set(r.detach().abs().round(decimals=1).unique().tolist()) <= {2.5, 2.6}
+    tv = mask.calc_tv_norm(torch.full((16,), 0.3).cuda().requires_grad_())
+    assert float(tv) == 0.0
+
+
+def test_find_masks_class_filter_empty(model, tmp_path, monkeypatch):
+    """classOI csv that selects no clip: no search runs, empty pickles are still written."""
+    import pickle as pk
+    import FindMasksComparison_I3D_smth as drv
+    import ivf_find_masks
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "sel.csv").write_text("5,7\n123,456\n")
+    loader = ivf_find_masks.SyntheticLoader(2, 2, (3, 16, 224, 224), 174, first_id=40)
+    masks = drv.find_masks(loader, model, {"batch_size": 2, "gradCamType": "guessed"}, 0.01, 0.02, 2, "central",
+                           "freeze", classOI=str(tmp_path / "sel.csv"), doGradCam=True, runTempMask=True, verbose=False)
+    assert masks == []
+    files = list((tmp_path / "results").glob("allTimeMaskResults_*"))
+    assert len(files) == 1 and pk.load(open(files[0], "rb")) == []

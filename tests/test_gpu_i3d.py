@@ -218,3 +218,36 @@ def test_search_trajectory_vs_reference(s16, golden):
     assert np.array_equal(final > 0.5, g['s16_mask'] > 0.5)
     rev = s16.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
     assert abs(float(rev) - float(g['s16_reverse_score'])) < 2e-3 * float(g['s16_reverse_score'])
+
+
+def test_i3d_s32_head_window_and_search():
+    """BASELINE configs[4] geometry: 32-frame 224x224 clips.  With stride_mod_layers="" the
+    reference's head AvgPool3d([2,7,7]) leaves a [B,K,3] output that it squeezes
+    inconsistently: the plan refuses that loudly.  With
+    stride_mod_layers="none" (no endpoint matches, window [4,7,7]) it must match the oracle."""
+    import ivf_engine
+    import ivf_lib as L
+    import ivf_recipe as R
+    from oracle import i3d_ref, mask_ref
+    with pytest.raises(L.IvfError):
+        ivf_engine.I3DEngine(174, (3, 32, 224, 224), max_batch=1, stride_mod_layers="")
+    eng = ivf_engine.I3DEngine(174, (3, 32, 224, 224), max_batch=1, stride_mod_layers="none", last_stride=1)
+    sd_np = R.i3d_state_dict(num_classes=174)
+    eng.load_state_dict(sd_np)
+    sd = R.to_torch(sd_np)
+    x = torch.from_numpy(R.clip(13, 3, 32, 224, 224))[None]
+    probs = eng.forward(x.cuda())
+    with torch.no_grad():
+        ref = i3d_ref.forward(x, sd, pool_kernel=(4, 7, 7), stride_mod_layers="none", last_stride=1)
+    assert rel_err(probs.cpu().numpy(), ref.numpy()) < 1e-3
+    target = int(ref[0].argmax())
+    assert int(probs[0].argmax()) == target
+
+    def score_fn(v):
+        return i3d_ref.forward(v, sd, pool_kernel=(4, 7, 7), stride_mod_layers="none", last_stride=1)[0, target]
+    init = torch.where(mask_ref.central_mask(32, 6) == 0, torch.tensor(-5.0), torch.tensor(5.0))
+    want = mask_ref.search_clip(x, score_fn, 0.01, 0.02, 2, init=init)
+    raw = init[None].cuda().contiguous()
+    traj, _ = eng.search(x.cuda(), [target], raw, 0.01, 0.02, 2)
+    got = traj[:, 0].cpu().numpy()
+    assert np.max(np.abs(got - want['traj'].numpy()) / np.abs(want['traj'].numpy())) < 1e-2
