@@ -17,7 +17,6 @@
 namespace ivf {
 
 constexpr int TH = 8, TW = 8;
-constexpr int ROWB = LDS_ROW_BF * 2;  // 80 bytes per LDS row per plane
 
 // Position (h, w) inside the 8 x 8 plane of a tile for plane-row p in [0,64): two 32-row MFMA
 // tiles (4 h-rows x 8 w each).  Which lane bit feeds which coordinate bit is free as long as
@@ -45,7 +44,9 @@ __device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
 // KS = 2 splits the taps of a chunk between two groups of waves (each wave then owns a
 // bigger output sub-tile, i.e. fewer LDS fragment reads per MFMA: what narrow outputs such as
 // the stem's 32-column backward-data need); the two partial sums meet in LDS at the end.
-template <int TT, int BN, int WROWS, int WCOLS, int KS>
+// BKH = channels per chunk: 32, or 16 to halve the LDS footprint so that TWO workgroups are
+// resident per CU and one's halo staging / weight pipeline overlaps the other's MFMAs.
+template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH>
 __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
                                                                                                 int tilesT,
                                                                                                 int tilesH,
@@ -54,7 +55,10 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
   constexpr int WM = BM / WROWS, WN = BN / WCOLS;
   constexpr int NT = WM * WN * KS * 64;
   constexpr int TM = WROWS / 32, TN = WCOLS / 32;
-  constexpr int BLOADS = (KS * BN * 4 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
+  constexpr int ROWB = (BKH + 8) * 2;   // bytes per LDS row per plane (80 / 48: conflict-free 16-byte reads)
+  constexpr int G4 = BKH / 4;           // float4 groups per halo row
+  constexpr int G8 = BKH / 8;           // 16-byte weight groups per row per plane
+  constexpr int BLOADS = (KS * BN * G8 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HT = TT + a.kT - 1, HH = TH + a.kH - 1, HW = TW + a.kW - 1;
@@ -124,9 +128,9 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
       int idx = tid + q * NT;
-      int grp = idx / (BN * 4);
-      int rem = idx - grp * (BN * 4);
-      int row = rem >> 2, g2 = rem & 3;
+      int grp = idx / (BN * G8);
+      int rem = idx - grp * (BN * G8);
+      int row = rem / G8, g2 = rem % G8;
       int tap = step + grp * nsteps;
       int n = n0 + row;
       int c = c0 + 8 * g2;
@@ -144,9 +148,9 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
       int idx = tid + q * NT;
-      int grp = idx / (BN * 4);
-      int rem = idx - grp * (BN * 4);
-      int row = rem >> 2, g2 = rem & 3;
+      int grp = idx / (BN * G8);
+      int rem = idx - grp * (BN * G8);
+      int row = rem / G8, g2 = rem % G8;
       if (grp < KS) {
         unsigned char* bh = b_base + (size_t)(buf * KS + grp) * 2 * BN * ROWB;
         unsigned char* bl = bh + (size_t)BN * ROWB;
@@ -244,9 +248,9 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
   // stage synchronously in batches of 4 loads)
   constexpr bool ASYNC = false;   // measured: issuing the next halo early buys nothing and costs 40+ registers
   constexpr int HRMAX = (TT + 3) * (TH + 3) * (TW + 3);
-  constexpr int NSTG = ASYNC ? (HRMAX * 8 + NT - 1) / NT : 4;
+  constexpr int NSTG = ASYNC ? (HRMAX * G4 + NT - 1) / NT : 4;
   float4 stg[NSTG];
-  const int ngroups = HR * 8;
+  const int ngroups = HR * G4;
   int stage_base = 0;
   auto stage_load = [&](int c0) {
 #pragma unroll
@@ -254,7 +258,7 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
       int idx = stage_base + u * NT + tid;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < ngroups) {
-        int row = idx >> 3, g = idx & 7;
+        int row = idx / G4, g = idx % G4;
         int c = c0 + 4 * g;
         int pos = rowoff[row];
         if (pos >= 0 && c < a.Cin && !(a.dbg & 512))
@@ -268,7 +272,7 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
     for (int u = 0; u < NSTG; ++u) {
       int idx = stage_base + u * NT + tid;
       if (idx < ngroups) {
-        int dst = (idx >> 3) * ROWB + 8 * (idx & 7);
+        int dst = (idx / G4) * ROWB + 8 * (idx % G4);
         uint2 h, l;
         split4(stg[u], &h, &l);
         *reinterpret_cast<uint2*>(a_hi + dst) = h;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
   };
   __syncthreads();   // rowoff table is complete
 
-  for (int c0 = 0; c0 < a.Cin; c0 += BK) {
+  for (int c0 = 0; c0 < a.Cin; c0 += BKH) {
     // weight tiles of the first PF taps start flying before the halo is staged
 #pragma unroll
     for (int u = 0; u < PF; ++u)
@@ -303,9 +307,9 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
     if constexpr (PIPE) load_a(0);
     // the next chunk's halo loads fly under this chunk's MFMAs (registers only; LDS is rewritten
     // after the barrier that ends the chunk)
-    if (async && c0 + BK < a.Cin) stage_load(c0 + BK);
+    if (async && c0 + BKH < a.Cin) stage_load(c0 + BKH);
 
-    const int cw = min(BK, a.Cin - c0);
+    const int cw = min(BKH, a.Cin - c0);
     const int nks = (cw + 15) >> 4;
     // tap loop unrolled by PF so the register ring is statically indexed: at tap (slot u)
     // the LDS buffer tap&1 holds its weights; slot u is refilled with tap+PF, and slot u+1's
@@ -409,9 +413,10 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
       wm * WROWS, n0 + wn * WCOLS, li, lh);
 }
 
-template <int TT, int BN, int WROWS, int WCOLS, int KS = 1>
+template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32>
 static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int NT = (TT * 64 / WROWS) * (BN / WCOLS) * KS * 64;
+  constexpr int ROWB = (BKH + 8) * 2;
   const int HR = (TT + a.kT - 1) * (TH + a.kH - 1) * (TW + a.kW - 1);
   const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
   if (KS == 2 && (size_t)TT * 64 * BN * 4 > (size_t)2 * HR * ROWB) {
@@ -424,7 +429,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS>),
+    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -433,7 +438,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
   const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
-  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
+  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -453,7 +458,10 @@ int conv_halo_supported(const ConvKArgs& a) {
 //  8: 2 192  32 x 96  1      9: 2 128  32 x 64  1    10: 2  96  32 x 96  1    11: 2  64  32 x 64  1
 // 12: 2  32  32 x 32  1     13: 2  64  64 x 64  2    14: 2 128  64 x 64  1
 // 15: 4  64  32 x 64  2     16: 4  96  32 x 96  2    17: 4  32  32 x 32  2
-int conv_halo_num_variants() { return 18; }
+// 16-channel chunks (two workgroups per CU):
+// 18: 2 192  32 x 96  1     19: 2 128  32 x 64  1    20: 4  96  32 x 96  1    21: 4  64  32 x 64  1
+// 22: 2  96  32 x 96  1
+int conv_halo_num_variants() { return 23; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -475,6 +483,11 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 15: return launch_halo<4, 64, 32, 64, 2>(a, 15, s);
     case 16: return launch_halo<4, 96, 32, 96, 2>(a, 16, s);
     case 17: return launch_halo<4, 32, 32, 32, 2>(a, 17, s);
+    case 18: return launch_halo<2, 192, 32, 96, 1, 16>(a, 18, s);
+    case 19: return launch_halo<2, 128, 32, 64, 1, 16>(a, 19, s);
+    case 20: return launch_halo<4, 96, 32, 96, 1, 16>(a, 20, s);
+    case 21: return launch_halo<4, 64, 32, 64, 1, 16>(a, 21, s);
+    case 22: return launch_halo<2, 96, 32, 96, 1, 16>(a, 22, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;
