@@ -119,6 +119,10 @@ typedef struct {
   int bsT, bsH, bsW;           /* d2s: block strides (forward strides, 1 or 2) */
   int math;                    /* IVF_MATH_FP32 or IVF_MATH_BF16X3; must match the weight pack */
   int variant;                 /* IVF_CONV_AUTO, or a kernel variant id from ivf_conv3d_variants() */
+  /* optional second input of a 1x1x1 conv: GEMM-K channels [K0, Cin) are read from in2 (same
+   * positions; row length in2_ld, channel offset in2_coff), channels [0, K0) from `in` */
+  int K0, in2_ld, in2_coff;
+  const float* in2;
 } ivf_conv3d_desc;
 
 /* Kernel variants: tile shapes of the plain implicit GEMM (IVF_CONV_IGEMM_BASE + 0..2) and of
@@ -145,6 +149,10 @@ int ivf_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int math);
 int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad, int kT,
                         int kH, int kW, int math, ivf_stream_t stream);
+/* Same, as rows [row0, row0+Cout) of a packed matrix with rows_total rows: several units that
+ * read the same input packed side by side so they run as one convolution. */
+int ivf_conv3d_pack_fwd_rows(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad, int kT,
+                             int kH, int kW, int row0, int rows_total, int math, ivf_stream_t stream);
 
 /* Geometry of the backward-data convolution produced by ivf_conv3d_pack_bwd. */
 typedef struct {
@@ -162,6 +170,14 @@ size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, i
 int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed, int Cout, int Cin,
                         int CinPad, int kT, int kH, int kW, int sT, int sH, int sW, int pT, int pH,
                         int pW, int math, ivf_conv3d_bwd_geom* geom, ivf_stream_t stream);
+
+/* The 1x1x1 units b0 / b1a / b2a of an Inception module read the same input, so their
+ * backward-data is ONE GEMM over the concatenated gradients [dY_b0 | dT_b1a | dT_b2a]:
+ * pack unit by unit, in any order, into a [CinPad][Ktotal] matrix (column offset koff; the
+ * unit ending at Ktotal also zeroes the row padding). */
+size_t ivf_conv3d_pack_bwd_fused1x1_elems(int Ktotal, int CinPad, int math);
+int ivf_conv3d_pack_bwd_fused1x1(const float* w_ref, const float* scale, float* w_packed, int Cout, int Cin,
+                                 int CinPad, int koff, int Ktotal, int math, ivf_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling / head */
 

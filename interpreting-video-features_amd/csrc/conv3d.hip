@@ -103,8 +103,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
                 (unsigned)wi < (unsigned)a.Wi;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
-        size_t off = ((size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + ci;
-        v = *reinterpret_cast<const float4*>(a.in + off);
+        size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
+        v = (a.in2 && kk >= a.K0)
+                ? *reinterpret_cast<const float4*>(a.in2 + pos * a.in2_ld + a.in2_coff + (kk - a.K0))
+                : *reinterpret_cast<const float4*>(a.in + pos * a.in_ld + a.in_coff + ci);
       }
       ra[j] = v;
     }
@@ -246,8 +248,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
                 (unsigned)wi < (unsigned)a.Wi;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
-        size_t off = ((size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + ci;
-        v = *reinterpret_cast<const float4*>(a.in + off);
+        size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
+        v = (a.in2 && kk >= a.K0)
+                ? *reinterpret_cast<const float4*>(a.in2 + pos * a.in2_ld + a.in2_coff + (kk - a.K0))
+                : *reinterpret_cast<const float4*>(a.in + pos * a.in_ld + a.in_coff + ci);
       }
       ra[j] = v;
     }
@@ -340,8 +344,9 @@ __device__ __forceinline__ void store_packed(float* out, int math, size_t row, i
   }
 }
 
+// rows [row0, row0 + Cout) of a packed matrix with rows_total rows (units packed side by side)
 __global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout,
-                                int Cin, int CinP, int taps, int ldw, int math) {
+                                int Cin, int CinP, int taps, int ldw, int math, int row0, int rows_total) {
   size_t total = (size_t)Cout * ldw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -350,12 +355,30 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__
     int ci = k % CinP;
     int tap = k / CinP;
     float v = (tap < taps && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
-    store_packed(out, math, co, k, ldw, Cout, v);
+    store_packed(out, math, row0 + co, k, ldw, rows_total, v);
   }
 }
 
 // backward-data pack for a stride-1 conv: a conv over dY with flipped taps,
 // Wb[ci][(tapf)*Cout + co] = scale[co] * W[co][ci][kT-1-kt][kH-1-kh][kW-1-kw]
+// 1x1x1 units of one Inception module packed side by side for a single backward GEMM:
+// out[ci][koff + co] = scale[co] * w[co][ci], rows of length ldw (columns outside [koff,koff+Cout)
+// belong to the other units or are padding zeroed by the first unit, koff == 0).
+__global__ void pack_bwd_fused1x1_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         float* __restrict__ out, int Cout, int Cin, int CinRows, int koff,
+                                         int ktotal, int ldw, int math) {
+  // every unit writes its own columns; the unit that ends at ktotal also zeroes the row padding
+  const int span = Cout + ((koff + Cout == ktotal) ? ldw - ktotal : 0);
+  size_t total = (size_t)CinRows * span;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int kk = i % span;
+    int ci = i / span;
+    float v = (kk < Cout && ci < Cin) ? (scale ? scale[kk] : 1.f) * w[(size_t)kk * Cin + ci] : 0.f;
+    store_packed(out, math, ci, koff + kk, ldw, CinRows, v);
+  }
+}
+
 __global__ void pack_bwd_s1_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                    float* __restrict__ out, int Cout, int Cin, int CinRows, int kT,
                                    int kH, int kW, int ldw, int math) {
@@ -483,9 +506,10 @@ static int check_desc(const ivf_conv3d_desc* d) {
   IVF_CHECK_ARG(d != nullptr, "conv3d: null descriptor");
   IVF_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0, "conv3d: bad input dims");
   IVF_CHECK_ARG(d->Cin > 0 && d->Cin % 4 == 0, "conv3d: Cin (%d) must be a positive multiple of 4", d->Cin);
-  IVF_CHECK_ARG(d->in_ld % 4 == 0 && d->in_coff % 4 == 0 && d->in_coff + d->Cin <= d->in_ld,
+  const int cin_first = d->in2 ? d->K0 : d->Cin;
+  IVF_CHECK_ARG(d->in_ld % 4 == 0 && d->in_coff % 4 == 0 && d->in_coff + cin_first <= d->in_ld,
                 "conv3d: input channel window [%d,+%d) must be 4-aligned inside ld %d", d->in_coff,
-                d->Cin, d->in_ld);
+                cin_first, d->in_ld);
   IVF_CHECK_ARG(d->Cout > 0 && d->out_coff >= 0, "conv3d: bad Cout");
   IVF_CHECK_ARG(d->kT > 0 && d->kH > 0 && d->kW > 0 && d->sT > 0 && d->sH > 0 && d->sW > 0,
                 "conv3d: bad kernel/stride");
@@ -517,6 +541,13 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
   a.K = d->kT * d->kH * d->kW * d->Cin;
   a.M = d->B * d->To * d->Ho * d->Wo;
+  a.in2 = d->in2; a.in2_ld = d->in2_ld; a.in2_coff = d->in2_coff; a.K0 = d->K0;
+  if (d->in2) {
+    IVF_CHECK_ARG(d->kT * d->kH * d->kW == 1, "conv3d: a second input is only defined for 1x1x1 convs");
+    IVF_CHECK_ARG(d->K0 > 0 && d->K0 < d->Cin && d->K0 % 4 == 0 && d->in2_ld % 4 == 0 && d->in2_coff % 4 == 0 &&
+                      d->in2_coff + (d->Cin - d->K0) <= d->in2_ld,
+                  "conv3d: second-input channel window must be 4-aligned inside its row");
+  }
   IVF_CHECK_ARG(d->math == 0 || d->math == 1, "conv3d: math must be 0 (fp32 MFMA) or 1 (split-bf16 x3)");
   a.ldw = pack_ldw(a.K, d->math);
   a.wbf = reinterpret_cast<const unsigned short*>(w_packed);
@@ -565,18 +596,24 @@ extern "C" size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH
   return (size_t)Cout * pack_ldw(kT * kH * kW * CinPad, math);
 }
 
-extern "C" int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin,
-                                   int CinPad, int kT, int kH, int kW, int math, ivf_stream_t stream) {
+extern "C" int ivf_conv3d_pack_fwd_rows(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad,
+                                        int kT, int kH, int kW, int row0, int rows_total, int math,
+                                        ivf_stream_t stream) {
   IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0 &&
-                    (math == 0 || math == 1),
+                    (math == 0 || math == 1) && row0 >= 0 && row0 + Cout <= rows_total,
                 "pack_fwd: bad args");
   int taps = kT * kH * kW;
   int ldw = pack_ldw(taps * CinPad, math);
   size_t total = (size_t)Cout * ldw;
-  hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)),
-                     dim3(256), 0, (hipStream_t)stream, w_ref, w_packed, Cout, Cin, CinPad, taps, ldw, math);
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_ref, w_packed, Cout, Cin, CinPad, taps, ldw, math, row0, rows_total);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
+}
+
+extern "C" int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin,
+                                   int CinPad, int kT, int kH, int kW, int math, ivf_stream_t stream) {
+  return ivf_conv3d_pack_fwd_rows(w_ref, w_packed, Cout, Cin, CinPad, kT, kH, kW, 0, Cout, math, stream);
 }
 
 extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float* w_packed,
@@ -639,4 +676,22 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   if (d->math == 1 && conv_halo_supported(a))
     for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
   return n;
+}
+
+extern "C" size_t ivf_conv3d_pack_bwd_fused1x1_elems(int Ktotal, int CinPad, int math) {
+  return (size_t)CinPad * pack_ldw(Ktotal, math);
+}
+
+extern "C" int ivf_conv3d_pack_bwd_fused1x1(const float* w_ref, const float* scale, float* w_packed, int Cout,
+                                            int Cin, int CinPad, int koff, int Ktotal, int math,
+                                            ivf_stream_t stream) {
+  IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && koff >= 0 && koff % 4 == 0 &&
+                    koff + Cout <= Ktotal && (math == 0 || math == 1),
+                "pack_bwd_fused1x1: bad args");
+  int ldw = pack_ldw(Ktotal, math);
+  size_t total = (size_t)CinPad * (Cout + ldw - Ktotal);
+  hipLaunchKernelGGL(pack_bwd_fused1x1_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_ref, scale, w_packed, Cout, Cin, CinPad, koff, Ktotal, ldw, math);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
 }

@@ -32,6 +32,11 @@ struct ConvKArgs {
   int ldw;
   long w_lo_off;
   int dbg;   // ablation switches for measurements (IVF_DBG env; 0 in normal use)
+  // second input for 1x1x1 convs: channels [K0, Cin) of the GEMM K dimension come from here
+  // (same positions, own row length / channel offset) -- lets one backward GEMM consume the
+  // gradients of several branches that live in different buffers
+  const float* in2;
+  int in2_ld, in2_coff, K0;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {

@@ -34,6 +34,15 @@ struct ConvLayer {
   size_t wf_elems = 0, wb_elems = 0;
   ivf_conv3d_bwd_geom geom{};
   int pad[3] = {0, 0, 0};   // forward front pads for the planned input size
+  // Inception 1x1x1 fusion (b0 / b1a / b2a share their input):
+  //  * b1a and b2a run forward as ONE conv writing the [b1a | b2a] buffer: the group's packed
+  //    weights / scale / shift live with b1a (grp_*), b2a's rows start at grp_row;
+  //  * all three run backward as ONE GEMM over [dY_b0 | dT_b1a | dT_b2a]: the packed matrix
+  //    lives with b0 (fus_*), each unit's columns start at fus_koff.
+  int grp_owner = -1, grp_row = 0, grp_rows = 0;
+  size_t grp_wf_off = 0, grp_scale_off = 0, grp_shift_off = 0, grp_wf_elems = 0;
+  int fus_owner = -1, fus_koff = 0, fus_ktotal = 0;
+  size_t fus_wb_off = 0, fus_wb_elems = 0;
 };
 
 struct Op {
@@ -45,6 +54,11 @@ struct Op {
   int k[3], s[3], p[3];
   size_t idx_off = 0;  // pool arg-max bytes offset (in bytes, inside workspace)
   int var_fwd = IVF_CONV_AUTO, var_bwd = IVF_CONV_AUTO;   // tuned kernel variants
+  bool fwd_group = false;   // forward: the fused b1a+b2a conv (weights: convs[conv].grp_*)
+  bool bwd_skip = false;    // backward: nothing to do here (covered by the fused GEMM below)
+  bool bwd_fused = false;   // backward: the fused b0+b1a+b2a GEMM; second gradient source = src2
+  int src2 = -1;
+  double flops_bwd_per_clip = 0.0;
   double flops_per_clip = 0.0;  // algorithmic: 2 * out positions * Cout * taps * REAL Cin (same for bwd-data)
   // backward bookkeeping for grad(src)
   bool bwd_accumulate = false, bwd_mask = false;
@@ -178,14 +192,30 @@ static int build_plan(ivf_i3d* n) {
     int l2a = b.add_conv_layer(nm + ".b2a", t[0], t[4], 1, 1, 1, 1, 1, 1, true);
     int l2b = b.add_conv_layer(nm + ".b2b", t[4], t[5], 3, 3, 3, 1, 1, 1, true);
     int l3b = b.add_conv_layer(nm + ".b3b", t[0], t[6], 1, 1, 1, 1, 1, 1, true);
-    int t1 = b.add_buf(nm + ".b1a", s.T, s.H, s.W, t[2], true);
-    int t2 = b.add_buf(nm + ".b2a", s.T, s.H, s.W, t[4], true);
+    int t12 = b.add_buf(nm + ".b12a", s.T, s.H, s.W, t[2] + t[4], true);   // [b1a | b2a]
     int t3 = b.add_buf(nm + ".b3a", s.T, s.H, s.W, t[0], false);
+    {
+      ConvLayer& A = n->convs[l1a];
+      ConvLayer& Bq = n->convs[l2a];
+      A.grp_owner = l1a; A.grp_row = 0; A.grp_rows = t[2] + t[4];
+      Bq.grp_owner = l1a; Bq.grp_row = t[2]; Bq.grp_rows = t[2] + t[4];
+      const int kt = t[1] + t[2] + t[4];
+      n->convs[l0].fus_owner = l0; n->convs[l0].fus_koff = 0; n->convs[l0].fus_ktotal = kt;
+      A.fus_owner = l0; A.fus_koff = t[1]; A.fus_ktotal = kt;
+      Bq.fus_owner = l0; Bq.fus_koff = t[1] + t[2]; Bq.fus_ktotal = kt;
+    }
     b.conv_op(l0, x, 0, y, 0);
-    b.conv_op(l1a, x, 0, t1, 0);
-    b.conv_op(l1b, t1, 0, y, t[1]);
-    b.conv_op(l2a, x, 0, t2, 0);
-    b.conv_op(l2b, t2, 0, y, t[1] + t[3]);
+    n->ops.back().bwd_fused = true;
+    n->ops.back().src2 = t12;
+    n->ops.back().flops_bwd_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[1] + t[2] + t[4]);
+    b.conv_op(l1a, x, 0, t12, 0);          // forward: the fused [b1a | b2a] conv
+    n->ops.back().fwd_group = true;
+    n->ops.back().bwd_skip = true;
+    n->ops.back().cout = t[2] + t[4];
+    n->ops.back().flops_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[2] + t[4]);
+    n->bufs[x].consumers--;               // its backward is part of the fused GEMM (counted via b0)
+    b.conv_op(l1b, t12, 0, y, t[1]);
+    b.conv_op(l2b, t12, t[2], y, t[1] + t[3]);
     b.pool_op(x, t3, 3, 3, 3, 1, 1, 1);
     b.conv_op(l3b, t3, 0, y, t[1] + t[3] + t[5]);
     x = y;
@@ -200,14 +230,34 @@ static int build_plan(ivf_i3d* n) {
     return IVF_ERR_UNSUPPORTED;
   }
 
-  // backward flags: walk ops in reverse; the first writer of grad(src) overwrites,
-  // later ones accumulate, the last applies the ReLU gate of src.
-  std::vector<int> seen(n->bufs.size(), 0);
-  for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
-    Op& o = n->ops[i];
-    o.bwd_accumulate = seen[o.src] > 0;
-    seen[o.src]++;
-    o.bwd_mask = (seen[o.src] == n->bufs[o.src].consumers) && n->bufs[o.src].relu_out;
+  // backward flags: walk ops in reverse; per (buffer, channel window) the first writer of the
+  // gradient overwrites, later ones accumulate, the last applies the ReLU gate of the buffer.
+  {
+    auto key = [](const Op& o) { return ((long long)o.src << 20) | o.src_coff; };
+    std::vector<std::pair<long long, int>> writers;   // (key, count)
+    auto find = [&](long long k) -> int& {
+      for (auto& w : writers)
+        if (w.first == k) return w.second;
+      writers.push_back({k, 0});
+      return writers.back().second;
+    };
+    for (const Op& o : n->ops)
+      if (!o.bwd_skip) find(key(o))++;
+    std::vector<std::pair<long long, int>> seen;
+    auto seen_of = [&](long long k) -> int& {
+      for (auto& w : seen)
+        if (w.first == k) return w.second;
+      seen.push_back({k, 0});
+      return seen.back().second;
+    };
+    for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
+      Op& o = n->ops[i];
+      if (o.bwd_skip) continue;
+      int& sc = seen_of(key(o));
+      o.bwd_accumulate = sc > 0;
+      sc++;
+      o.bwd_mask = (sc == find(key(o))) && n->bufs[o.src].relu_out;
+    }
   }
 
   // ---- weights arena layout (floats)
@@ -230,6 +280,16 @@ static int build_plan(ivf_i3d* n) {
     L.wb_off = take(L.wb_elems);
     L.scale_off = take(L.cout);
     L.shift_off = take(L.cout);
+    if (L.grp_owner == (int)i) {
+      L.grp_wf_elems = ivf_conv3d_pack_fwd_elems(L.grp_rows, L.cinp, 1, 1, 1, c.math);
+      L.grp_wf_off = take(L.grp_wf_elems);
+      L.grp_scale_off = take(L.grp_rows);
+      L.grp_shift_off = take(L.grp_rows);
+    }
+    if (L.fus_owner == (int)i) {
+      L.fus_wb_elems = ivf_conv3d_pack_bwd_fused1x1_elems(L.fus_ktotal, L.cinp, c.math);
+      L.fus_wb_off = take(L.fus_wb_elems);
+    }
   }
   n->weights_floats = w;
 
@@ -281,6 +341,7 @@ static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->relu = 1;
   d->math = n->cfg.math;
   d->variant = o.var_fwd;
+  (void)0;   // (for the fused [b1a | b2a] op o.cout already spans both units)
 }
 
 static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
@@ -296,6 +357,17 @@ static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->mask_ld = s.C; d->mask_coff = o.src_coff;
   d->math = n->cfg.math;
   d->variant = o.var_bwd;
+  if (o.bwd_fused) {
+    // one GEMM over [dY_b0 | dT_b1a | dT_b2a] -> d(input of the module)
+    const ActBuf& t12 = n->bufs[o.src2];
+    d->Cin = L.fus_ktotal;
+    d->K0 = o.cout;
+    d->in2_ld = t12.C; d->in2_coff = 0;
+    d->in2 = n->grad(o.src2);
+    d->To = s.T; d->Ho = s.H; d->Wo = s.W;
+    d->Cout = o.cin;
+    return;
+  }
   if (L.geom.d2s) {
     d->d2s = 1;
     d->bsT = o.s[0]; d->bsH = o.s[1]; d->bsW = o.s[2];
@@ -334,8 +406,12 @@ static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream
       ivf_conv3d_desc d;
       fill_conv_fwd(n, o, b, &d);
       prof_set_flops(o.flops_per_clip * b);
-      IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off,
-                               n->warena + L.shift_off, nullptr, n->act(o.dst), s));
+      if (o.fwd_group)
+        IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.grp_wf_off, n->warena + L.grp_scale_off,
+                                 n->warena + L.grp_shift_off, nullptr, n->act(o.dst), s));
+      else
+        IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off,
+                                 n->warena + L.shift_off, nullptr, n->act(o.dst), s));
     } else {
       ivf_pool3d_desc d;
       fill_pool(n, o, b, &d);
@@ -365,14 +441,15 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
                              n->cfg.num_classes, n->cfg.softmax, 1, s));
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     const Op& o = n->ops[i];
+    if (o.bwd_skip) continue;
     const float* gate = o.bwd_mask ? n->act(o.src) : nullptr;
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_bwd(n, o, b, &d);
-      prof_set_flops(o.flops_per_clip * b);
-      IVF_PROPAGATE(ivf_conv3d(&d, n->grad(o.dst), n->warena + L.wb_off, nullptr, nullptr, gate,
-                               n->grad(o.src), s));
+      prof_set_flops((o.bwd_fused ? o.flops_bwd_per_clip : o.flops_per_clip) * b);
+      IVF_PROPAGATE(ivf_conv3d(&d, n->grad(o.dst), n->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr,
+                               nullptr, gate, n->grad(o.src), s));
     } else {
       ivf_pool3d_desc d;
       fill_pool(n, o, b, &d);
@@ -533,6 +610,20 @@ extern "C" int ivf_i3d_load_conv(ivf_i3d_t* net, int i, const float* w, const fl
   IVF_PROPAGATE(ivf_conv3d_pack_bwd(w, A + L.scale_off, A + L.wb_off, L.cout, L.cin, L.cinp, L.k[0], L.k[1],
                                     L.k[2], L.s[0], L.s[1], L.s[2], L.pad[0], L.pad[1], L.pad[2], net->cfg.math,
                                     &L.geom, s));
+  if (L.grp_owner >= 0) {
+    const ConvLayer& G = net->convs[L.grp_owner];
+    IVF_PROPAGATE(ivf_conv3d_pack_fwd_rows(w, A + G.grp_wf_off, L.cout, L.cin, L.cinp, 1, 1, 1, L.grp_row,
+                                           G.grp_rows, net->cfg.math, s));
+    IVF_CHECK_HIP(hipMemcpyAsync(A + G.grp_scale_off + L.grp_row, A + L.scale_off, (size_t)L.cout * 4,
+                                 hipMemcpyDeviceToDevice, s));
+    IVF_CHECK_HIP(hipMemcpyAsync(A + G.grp_shift_off + L.grp_row, A + L.shift_off, (size_t)L.cout * 4,
+                                 hipMemcpyDeviceToDevice, s));
+  }
+  if (L.fus_owner >= 0) {
+    const ConvLayer& F = net->convs[L.fus_owner];
+    IVF_PROPAGATE(ivf_conv3d_pack_bwd_fused1x1(w, A + L.scale_off, A + F.fus_wb_off, L.cout, L.cin, L.cinp, L.fus_koff,
+                                               L.fus_ktotal, net->cfg.math, s));
+  }
   net->loaded[i] = true;
   return IVF_OK;
 }
@@ -716,6 +807,7 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
     if (o.type != Op::CONV) continue;
     const ConvLayer& L = net->convs[o.conv];
     for (int dir = 0; dir < 2 && rc == IVF_OK; ++dir) {
+      if (dir == 1 && o.bwd_skip) continue;
       ivf_conv3d_desc d;
       int ids[32];
       int* slot = dir == 0 ? &o.var_fwd : &o.var_bwd;
@@ -727,10 +819,14 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
       for (int k = 0; k < nv; ++k) {
         d.variant = ids[k];
         auto run = [&]() {
-          return dir == 0 ? ivf_conv3d(&d, net->act(o.src), net->warena + L.wf_off, net->warena + L.scale_off,
-                                       net->warena + L.shift_off, nullptr, net->act(o.dst), s)
-                          : ivf_conv3d(&d, net->grad(o.dst), net->warena + L.wb_off, nullptr, nullptr,
-                                       o.bwd_mask ? net->act(o.src) : nullptr, net->grad(o.src), s);
+          if (dir == 0)
+            return o.fwd_group ? ivf_conv3d(&d, net->act(o.src), net->warena + L.grp_wf_off,
+                                            net->warena + L.grp_scale_off, net->warena + L.grp_shift_off, nullptr,
+                                            net->act(o.dst), s)
+                               : ivf_conv3d(&d, net->act(o.src), net->warena + L.wf_off, net->warena + L.scale_off,
+                                            net->warena + L.shift_off, nullptr, net->act(o.dst), s);
+          return ivf_conv3d(&d, net->grad(o.dst), net->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr,
+                            nullptr, o.bwd_mask ? net->act(o.src) : nullptr, net->grad(o.src), s);
         };
         if (run() != IVF_OK) continue;          // variant not applicable to this shape
         (void)hipEventRecord(e0, s);

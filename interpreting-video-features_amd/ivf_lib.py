@@ -27,7 +27,8 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "Ti", "Hi", "Wi", "Cin", "in_ld", "in_coff", "To", "Ho", "Wo", "Cout", "out_ld",
         "out_coff", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "relu", "accumulate",
-        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math", "variant")]
+        "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math", "variant",
+        "K0", "in2_ld", "in2_coff")] + [("in2", c_void_p)]
 
 
 class BwdGeom(Structure):
@@ -72,8 +73,11 @@ _SIGS = {
     "ivf_bn_fold": (c_int, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "ivf_conv3d_pack_fwd_elems": (c_size_t, [_I] * 6),
     "ivf_conv3d_pack_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ivf_conv3d_pack_fwd_rows": (c_int, [_P, _P] + [_I] * 9 + [_P]),
     "ivf_conv3d_pack_bwd_elems": (c_size_t, [_I] * 12),
     "ivf_conv3d_pack_bwd": (c_int, [_P, _P, _P] + [_I] * 13 + [POINTER(BwdGeom), _P]),
+    "ivf_conv3d_pack_bwd_fused1x1_elems": (c_size_t, [_I, _I, _I]),
+    "ivf_conv3d_pack_bwd_fused1x1": (c_int, [_P, _P, _P] + [_I] * 6 + [_P]),
     "ivf_maxpool3d_fwd": (c_int, [POINTER(PoolDesc), _P, _P, _P, _P]),
     "ivf_maxpool3d_bwd": (c_int, [POINTER(PoolDesc), _P, _P, _P, _P, _I, _P]),
     "ivf_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
