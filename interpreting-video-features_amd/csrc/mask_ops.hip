@@ -134,6 +134,61 @@ __global__ __launch_bounds__(256) void freeze_bwd_kernel(
   }
 }
 
+// channels-last gradient (row of 4 floats per pixel, C <= 4) and no dX: one thread per
+// pixel loads each frame's 16-byte gradient once and reuses it for all channels
+template <int TT>
+__global__ __launch_bounds__(256) void freeze_bwd_cl4_kernel(
+    const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ g,
+    float* __restrict__ partial, int B, int C, int T, int HW, int mask_per_clip, int blocks_per_clip) {
+  const int b = blockIdx.x / blocks_per_clip;
+  const int blk = blockIdx.x % blocks_per_clip;
+  const float* mp = mask + (mask_per_clip ? (size_t)b * T : 0);
+  float acc[TT];
+#pragma unroll
+  for (int u = 0; u < TT; ++u) acc[u] = 0.f;
+  for (int px = blk * blockDim.x + threadIdx.x; px < HW; px += blocks_per_clip * blockDim.x) {
+    float4 gv[TT];
+#pragma unroll
+    for (int u = 0; u < TT; ++u)
+      if (u < T) gv[u] = *reinterpret_cast<const float4*>(g + ((size_t)(b * T + u) * HW + px) * 4);
+    for (int c = 0; c < C; ++c) {
+      const float* xp = x + ((size_t)(b * C + c) * T) * HW + px;
+      float xv[TT], pv[TT];
+#pragma unroll
+      for (int u = 0; u < TT; ++u) {
+        if (u < T) {
+          xv[u] = xp[(size_t)u * HW];
+          pv[u] = u ? (1.f - mp[u]) * xv[u] + mp[u] * pv[u - 1] : xv[u];
+        }
+      }
+      float G = 0.f;
+#pragma unroll
+      for (int u = TT - 1; u >= 0; --u) {
+        if (u < T) {
+          float gc = c == 0 ? gv[u].x : (c == 1 ? gv[u].y : (c == 2 ? gv[u].z : gv[u].w));
+          float mnext = (u + 1 < T) ? mp[u + 1] : 0.f;
+          G = gc + mnext * G;
+          if (u > 0) acc[u] += (pv[u - 1] - xv[u]) * G;
+        }
+      }
+    }
+  }
+  __shared__ float red[4][TT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < TT; ++u) {
+    float v = acc[u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wave][u] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {
+    int u = threadIdx.x;
+    partial[((size_t)b * blocks_per_clip + blk) * T + u] = red[0][u] + red[1][u] + red[2][u] + red[3][u];
+  }
+}
+
 __global__ void freeze_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dmask,
                                          int B, int T, int blocks_per_clip) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -395,7 +450,14 @@ extern "C" int ivf_freeze_bwd(const float* x, const float* mask, const float* g,
   float* partial = (float*)workspace;
   const int bpc = FREEZE_BWD_BLOCKS_PER_CLIP;
   dim3 grid(B * bpc), block(256);
-  if (T <= 16)
+  if (g_cpad == 4 && C <= 4 && !dx && T <= 32) {
+    if (T <= 16)
+      hipLaunchKernelGGL(freeze_bwd_cl4_kernel<16>, grid, block, 0, s, x, mask, g, partial, B, C, T, HW,
+                         mask_per_clip, bpc);
+    else
+      hipLaunchKernelGGL(freeze_bwd_cl4_kernel<32>, grid, block, 0, s, x, mask, g, partial, B, C, T, HW,
+                         mask_per_clip, bpc);
+  } else if (T <= 16)
     hipLaunchKernelGGL(freeze_bwd_kernel<16>, grid, block, 0, s, x, mask, g, dx, partial, B, C, T, HW,
                        mask_per_clip, g_cpad, bpc);
   else if (T <= 32)

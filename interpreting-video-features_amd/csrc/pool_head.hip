@@ -292,6 +292,213 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------- 3x3x3 stride-1 'same' pools
+// The Inception branch pools (k 3, s 1, p 1).  One thread owns an image column (w, 4
+// channels) of a TH-row tile and walks the planes of the clip.  The window maximum is
+// separable and so is its first-occurrence arg-max (lowest kt, then kh, then kw with the
+// maximum value): row maxima over kw (3 loads per staged row, neighbours served by L1), a
+// rolling max over kh, and a rolling max over kt kept in registers -- 27/7 loads per output
+// instead of 27, no LDS, no barriers.
+constexpr int S1_TH = 7;
+
+__device__ __forceinline__ bool pool_takes(float v, float best) { return v > best || v != v; }
+
+__global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             unsigned char* __restrict__ idx, PoolArgs a, int G,
+                                                             int nH, int slabs) {
+  int blk = blockIdx.x;
+  const int slab = blk % slabs; blk /= slabs;
+  const int ih = blk % nH;
+  const int b = blk / nH;
+  const int g = threadIdx.x % G, w = threadIdx.x / G;
+  const int c = slab * G * 4 + 4 * g;
+  if (w >= a.Wi || c >= a.C) return;
+  const int h0 = ih * S1_TH;
+  float pv1[S1_TH][4], pv2[S1_TH][4];
+  unsigned pi1[S1_TH], pi2[S1_TH];   // 2-D taps (kh*3+kw), one byte per channel
+#pragma unroll
+  for (int h = 0; h < S1_TH; ++h) {
+    pi1[h] = pi2[h] = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pv1[h][q] = pv2[h][q] = 0.f;
+  }
+  for (int t = 0; t <= a.Ti; ++t) {
+    float cv[S1_TH][4];
+    unsigned ci[S1_TH];
+    if (t < a.Ti) {
+      float rv[S1_TH + 2][4];
+      unsigned ri[S1_TH + 2];
+#pragma unroll
+      for (int r = 0; r < S1_TH + 2; ++r) {
+        const int hi = h0 - 1 + r;
+        float4 v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int wi = w - 1 + j;
+          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+            v[j] = *reinterpret_cast<const float4*>(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
+                                                    a.in_coff + c);
+        }
+        const float v0[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+        const float v1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+        const float v2[4] = {v[2].x, v[2].y, v[2].z, v[2].w};
+        unsigned pk = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float best = v0[q];
+          unsigned k = 0u;
+          if (pool_takes(v1[q], best)) { best = v1[q]; k = 1u; }
+          if (pool_takes(v2[q], best)) { best = v2[q]; k = 2u; }
+          rv[r][q] = best;
+          pk |= k << (8 * q);
+        }
+        ri[r] = pk;
+      }
+#pragma unroll
+      for (int h = 0; h < S1_TH; ++h) {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float best = rv[h][q];
+          unsigned k = (ri[h] >> (8 * q)) & 0xffu;
+          if (pool_takes(rv[h + 1][q], best)) { best = rv[h + 1][q]; k = 3u + ((ri[h + 1] >> (8 * q)) & 0xffu); }
+          if (pool_takes(rv[h + 2][q], best)) { best = rv[h + 2][q]; k = 6u + ((ri[h + 2] >> (8 * q)) & 0xffu); }
+          cv[h][q] = best;
+          pk |= k << (8 * q);
+        }
+        ci[h] = pk;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < S1_TH; ++h) {
+        ci[h] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cv[h][q] = 0.f;
+      }
+    }
+    if (t >= 1) {
+      const int to = t - 1;
+#pragma unroll
+      for (int h = 0; h < S1_TH; ++h) {
+        const int ho = h0 + h;
+        if (ho >= a.Ho) continue;
+        float o[4];
+        unsigned pk = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float best = pv2[h][q];
+          unsigned k = (pi2[h] >> (8 * q)) & 0xffu;
+          if (pool_takes(pv1[h][q], best)) { best = pv1[h][q]; k = 9u + ((pi1[h] >> (8 * q)) & 0xffu); }
+          if (pool_takes(cv[h][q], best)) { best = cv[h][q]; k = 18u + ((ci[h] >> (8 * q)) & 0xffu); }
+          o[q] = best;
+          pk |= k << (8 * q);
+        }
+        const size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + w;
+        *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (idx) *reinterpret_cast<unsigned*>(idx + m * a.C + c) = pk;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < S1_TH; ++h) {
+      pi2[h] = pi1[h];
+      pi1[h] = ci[h];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pv2[h][q] = pv1[h][q]; pv1[h][q] = cv[h][q]; }
+    }
+  }
+}
+
+// backward of the same pools as a gather: the thread of input cell (h, w) reads the (dY,
+// arg-max) of the 3x3 outputs around it plane by plane and adds dY where the recorded tap
+// points back at its cell; three accumulators (input planes to-1, to, to+1) roll along t.
+// The 27 compare-select-adds per element bound this kernel (VALU), so it is written for
+// occupancy: ~60 registers, loads of neighbouring cells served by L1.  Contributions arrive
+// in ascending (to, ho, wo) order, as in the other backward kernels.
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const float* __restrict__ dy,
+                                                             const unsigned char* __restrict__ idx,
+                                                             float* __restrict__ dx,
+                                                             const float* __restrict__ relu_mask, int accumulate,
+                                                             PoolArgs a, int G, int slabs) {
+  int blk = blockIdx.x;
+  const int slab = blk % slabs; blk /= slabs;
+  const int h = blk % a.Hi;
+  const int b = blk / a.Hi;
+  const int g = threadIdx.x % G, w = threadIdx.x / G;
+  const int c = slab * G * 4 + 4 * g;
+  if (w >= a.Wi || c >= a.C) return;
+  float acc[3][4];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = 0.f;
+  auto store_plane = [&](int ti) {
+    const size_t m = ((size_t)(b * a.Ti + ti) * a.Hi + h) * a.Wi + w;
+    float* dst = dx + m * a.in_ld + a.in_coff + c;
+    float o[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+    if (accumulate) {
+      float4 old = *reinterpret_cast<const float4*>(dst);
+      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+    }
+    if (relu_mask) {
+      float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + c);
+      if (!(k.x > 0.f)) o[0] = 0.f;
+      if (!(k.y > 0.f)) o[1] = 0.f;
+      if (!(k.z > 0.f)) o[2] = 0.f;
+      if (!(k.w > 0.f)) o[3] = 0.f;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  for (int to = 0; to < a.To; ++to) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ho = h - 1 + r;
+      const int kh = 2 - r;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int wo = w - 1 + j;
+        const int kw = 2 - j;
+        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned u = 0xffffffffu;   // matches no tap
+        if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+          const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+          gq = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + c);
+          u = *reinterpret_cast<const unsigned*>(idx + mo * a.C + c);
+        }
+        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          // output plane `to` reaches input plane to + kt - 1, kept in acc[kt]
+          const unsigned tap = (unsigned)((kt * 3 + kh) * 3 + kw);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (((u >> (8 * q)) & 0xffu) == tap) acc[kt][q] += gv[q];
+        }
+      }
+    }
+    if (to >= 1) store_plane(to - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0][q] = acc[1][q];
+      acc[1][q] = acc[2][q];
+      acc[2][q] = 0.f;
+    }
+  }
+  store_plane(a.Ti - 1);
+}
+
+static bool pool_is_3s1(const PoolArgs& a) {
+  return a.kT == 3 && a.kH == 3 && a.kW == 3 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 1 && a.pH == 1 &&
+         a.pW == 1 && a.To == a.Ti && a.Ho == a.Hi && a.Wo == a.Wi;
+}
+// channel groups (of 4) per workgroup: ~224 threads, at least a 128-byte run per position
+static int pool_3s1_groups(const PoolArgs& a) {
+  int G = 8;
+  while (G < 64 && a.Wi * G * 2 <= 256 && G * 4 < a.C) G *= 2;
+  while (G > 1 && a.Wi * G > 256) G /= 2;
+  return G;
+}
+
 // tile choice: ~128-256 tile cells, staged region <= ~450 cells (<= 64 KB of LDS)
 static void pool_fwd_tile(const PoolArgs& a, PoolTile* t) {
   t->tT = a.kT == 1 ? 1 : (a.sT == 1 ? 2 : 2);
@@ -318,7 +525,7 @@ static void pool_bwd_tile(const PoolArgs& a, PoolTile* t) {
 // ---------------------------------------------------------------- head
 // One block per clip.  pooled[c] = mean over the npos feature cells;
 // logits[k] = bias[k] + sum_c pooled[c] W[k][c]; probs = softmax(logits).
-__global__ __launch_bounds__(256) void head_fwd_kernel(
+__global__ __launch_bounds__(1024) void head_fwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ pooled_out, float* __restrict__ logits, float* __restrict__ probs, int npos,
     int C, int K, int softmax) {
@@ -591,6 +798,15 @@ extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float
   // measured on MI355X (16-channel slabs): the tiled form wins 1.4x for the stride-1 3x3x3
   // Inception pools (the direct kernel saturates L2 with its 27x re-reads) and loses for the
   // strided pools, whose windows barely overlap
+  static const bool no_s1 = getenv("IVF_POOL_NO_S1") != nullptr;
+  if (!direct && !no_s1 && pool_is_3s1(a) && a.Wi <= 256) {
+    const int G = pool_3s1_groups(a), nH = cdiv(a.Hi, S1_TH), slabs = cdiv(a.C, 4 * G);
+    const int threads = ((a.Wi * G + 63) / 64) * 64;
+    hipLaunchKernelGGL(maxpool3s1_fwd_kernel, dim3((unsigned)(a.B * nH * slabs)), dim3(threads), 0,
+                       (hipStream_t)stream, x, y, argmax, a, G, nH, slabs);
+    IVF_CHECK_LAUNCH();
+    return IVF_OK;
+  }
   const bool tiled_fwd = a.sT == 1 && a.sH == 1 && a.sW == 1;
   if (!direct && tiled_fwd && shm <= 64 * 1024) {
     long blocks = (long)a.B * t.nT * t.nH * t.nW * t.slabs;
@@ -616,6 +832,16 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
   PoolTile t;
   pool_bwd_tile(a, &t);
   size_t shm = (size_t)t.rT * t.rH * t.rW * (POOL_ROW * sizeof(float) + POOL_SLAB);
+  static const bool no_s1 = getenv("IVF_POOL_NO_S1") != nullptr;
+  if (!direct && !no_s1 && pool_is_3s1(a) && a.Wi <= 256) {
+    const int G = pool_3s1_groups(a), nH = cdiv(a.Hi, S1_TH), slabs = cdiv(a.C, 4 * G);
+    const int threads = ((a.Wi * G + 63) / 64) * 64;
+    (void)nH;
+    hipLaunchKernelGGL(maxpool3s1_bwd_kernel, dim3((unsigned)(a.B * a.Hi * slabs)), dim3(threads), 0,
+                       (hipStream_t)stream, dy, argmax, dx, relu_mask, accumulate, a, G, slabs);
+    IVF_CHECK_LAUNCH();
+    return IVF_OK;
+  }
   // measured (16-channel slabs): the tiled gather wins 1.3-1.6x for every pool of the net
   if (!direct && shm <= 80 * 1024) {
     static bool attr_set = false;
@@ -644,7 +870,7 @@ extern "C" int ivf_head_fwd(const float* feat, const float* w, const float* bias
   IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K + 8) * 4 <= 64 * 1024,
                 "head_fwd: bad dims");
   size_t shm = (size_t)(C + K + 8) * sizeof(float);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, feat, w, bias, pooled,
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(1024), shm, (hipStream_t)stream, feat, w, bias, pooled,
                      logits, probs, npos, C, K, softmax);
   IVF_CHECK_LAUNCH();
   return IVF_OK;

@@ -48,7 +48,9 @@ def test_freeze_fwd_bwd_vs_reference(T, golden):
     gcl = torch.zeros(2, T, 12, 20, 4, device='cuda')
     gcl[..., :3] = gy.permute(0, 2, 3, 4, 1)
     dm2, _ = _freeze_bwd(x, m, gcl.contiguous(), cpad=4, want_dx=False)
-    assert torch.equal(dm2, dm)
+    # the channels-last kernel sums pixels in a different order (one thread per pixel)
+    assert rel_err(dm2.cpu().numpy(), dm.cpu().numpy()) < 1e-6
+    assert rel_err(dm2.sum(0).cpu().numpy(), g[f'freeze{T}_dm']) < 1e-5
 
 
 def test_freeze_per_clip_masks_match_oracle():

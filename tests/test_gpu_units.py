@@ -156,3 +156,46 @@ def test_maxpool_fwd_bwd(name, golden):
     # same winners (ties incl. zero padding) -> identical routing; sums of <= 27 terms
     assert np.array_equal(dx != 0, ref != 0)
     assert np.allclose(dx, ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("thw,C", [((4, 16, 9), 40), ((8, 28, 28), 32), ((2, 7, 7), 136), ((1, 3, 2), 8)])
+def test_maxpool_333_stride1_many_tiles_with_ties(thw, C):
+    """The separable 3x3x3 stride-1 kernels (several row tiles, partial channel slabs) against
+    torch's CPU max_pool3d over the zero-padded input (models/I3D_doubled.py:8-40), on inputs
+    quantised so that windows hold many exact ties: forward bit-exact, backward routing
+    identical."""
+    import torch.nn.functional as F
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(7)
+    B = 2
+    x = torch.relu(torch.round(torch.randn((B, C) + thw, generator=gen) * 3) / 3)
+    gy = torch.randn((B, C) + thw, generator=gen)
+    xr = x.clone().requires_grad_()
+    y = F.max_pool3d(F.pad(xr, (1, 1, 1, 1, 1, 1)), 3, 1)
+    y.backward(gy)
+    xcl = to_cl(x.cuda(), C)
+    ycl = torch.zeros_like(xcl)
+    idx = torch.zeros(xcl.shape, dtype=torch.uint8, device='cuda')
+    d = L.PoolDesc()
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, *thw, C, C, 0
+    d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *thw, C, 0
+    d.kT = d.kH = d.kW = 3
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = 1
+    L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(ycl), L.ptr(idx), L.stream()))
+    assert np.array_equal(from_cl(ycl, C).cpu().numpy(), y.detach().numpy())
+    dxcl = torch.full_like(xcl, float('nan'))
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy.cuda(), C)), L.ptr(idx), L.ptr(dxcl), None, 0,
+                                  L.stream()))
+    dx = from_cl(dxcl, C).cpu().numpy()
+    ref = xr.grad.numpy()
+    assert np.array_equal(dx != 0, ref != 0)
+    assert np.allclose(dx, ref, rtol=1e-5, atol=1e-6)
+    # accumulate + ReLU gate path
+    base = torch.randn_like(xcl)
+    acc = base.clone()
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy.cuda(), C)), L.ptr(idx), L.ptr(acc), L.ptr(xcl), 1,
+                                  L.stream()))
+    want = torch.where(xcl > 0, base + dxcl, torch.zeros_like(base))
+    assert torch.allclose(acc, want, rtol=1e-6, atol=1e-6)

@@ -26,4 +26,4 @@ for name, (B, T, H, W, C, k, s) in cases.items():
         for _ in range(10): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        print(f"{name:8s} {label} {ms*1e3:8.1f} us  {bytes_/ms/1e9:6.2f} TB/s (compulsory bytes)   env={os.environ.get('IVF_POOL_DIRECT','')}{os.environ.get('IVF_POOL_TILED_FWD','')}")
+        print(f"{name:8s} {label} {ms*1e3:8.1f} us  {bytes_/ms/1e9:6.2f} TB/s (compulsory bytes)   no_s1={os.environ.get('IVF_POOL_NO_S1','')}")
