@@ -185,6 +185,10 @@ typedef struct {
   int B, Ti, Hi, Wi, C, in_ld, in_coff;
   int To, Ho, Wo, out_ld, out_coff;
   int kT, kH, kW, sT, sH, sW, pT, pH, pW; /* front ZERO padding (I3D_doubled.py:36-39) */
+  /* forward only: record arg-max 255 ("no route") for windows whose maximum is not > 0.
+   * When x is a ReLU output and the gradient is wanted below that ReLU, the backward then
+   * needs no relu_mask: a cell with x <= 0 can only win a window whose maximum is <= 0. */
+  int gate_nonpos;
 } ivf_pool3d_desc;
 
 /* MaxPool3dSamePadding.forward, I3D_doubled.py:15-40; argmax [positions_out][C] uint8

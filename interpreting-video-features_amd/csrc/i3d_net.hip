@@ -388,6 +388,9 @@ static void fill_pool(const ivf_i3d* n, const Op& o, int b, ivf_pool3d_desc* d) 
   d->To = t.T; d->Ho = t.H; d->Wo = t.W; d->out_ld = t.C; d->out_coff = 0;
   d->kT = o.k[0]; d->kH = o.k[1]; d->kW = o.k[2]; d->sT = o.s[0]; d->sH = o.s[1]; d->sW = o.s[2];
   d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
+  // a pool that owes its input gradient the ReLU gate marks dead windows in the forward
+  // instead of re-reading the activation in the backward
+  d->gate_nonpos = o.bwd_mask;
 }
 
 static int check_ready(const ivf_i3d* n, int b) {
@@ -453,8 +456,10 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
     } else {
       ivf_pool3d_desc d;
       fill_pool(n, o, b, &d);
+      // sole writer of a ReLU output's gradient: gated through the arg-max record (fill_pool);
+      // with other writers before it the accumulated sum still needs the explicit gate
       IVF_PROPAGATE(ivf_maxpool3d_bwd(&d, n->grad(o.dst), n->at<unsigned char>(o.idx_off), n->grad(o.src),
-                                      gate, o.bwd_accumulate, s));
+                                      o.bwd_accumulate ? gate : nullptr, o.bwd_accumulate, s));
     }
   }
   return IVF_OK;

@@ -15,6 +15,7 @@ struct PoolArgs {
   int B, Ti, Hi, Wi, C, in_ld, in_coff;
   int To, Ho, Wo, out_ld, out_coff;
   int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+  int dead;   // forward: arg-max 255 where the window maximum is not > 0
 };
 
 // forward: scan the window in (kt,kh,kw) order over the ZERO-padded input
@@ -65,6 +66,10 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + 4 * c4) =
         make_float4(best[0], best[1], best[2], best[3]);
     if (idx) {
+      if (a.dead)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (!(best[q] > 0.f)) bi[q] = 255;
       uchar4 u = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
       *reinterpret_cast<uchar4*>(idx + m * a.C + 4 * c4) = u;
     }
@@ -199,7 +204,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
     size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
     *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + c0 + 4 * g) =
         make_float4(best[0], best[1], best[2], best[3]);
-    if (idx) *reinterpret_cast<uchar4*>(idx + m * a.C + c0 + 4 * g) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    if (idx) {
+      if (a.dead)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (!(best[q] > 0.f)) bi[q] = 255;
+      *reinterpret_cast<uchar4*>(idx + m * a.C + c0 + 4 * g) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
   }
 }
 
@@ -396,7 +407,13 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __rest
         }
         const size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + w;
         *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
-        if (idx) *reinterpret_cast<unsigned*>(idx + m * a.C + c) = pk;
+        if (idx) {
+          if (a.dead)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (!(o[q] > 0.f)) pk |= 0xffu << (8 * q);
+          *reinterpret_cast<unsigned*>(idx + m * a.C + c) = pk;
+        }
       }
     }
 #pragma unroll
@@ -778,7 +795,7 @@ static PoolArgs to_args(const ivf_pool3d_desc* d) {
   a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.in_ld = d->in_ld;
   a.in_coff = d->in_coff; a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.out_ld = d->out_ld;
   a.out_coff = d->out_coff; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.sT = d->sT; a.sH = d->sH;
-  a.sW = d->sW; a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
+  a.sW = d->sW; a.pT = d->pT; a.pH = d->pH; a.pW = d->pW; a.dead = d->gate_nonpos;
   return a;
 }
 

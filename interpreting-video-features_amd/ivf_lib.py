@@ -38,7 +38,7 @@ class BwdGeom(Structure):
 class PoolDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "Ti", "Hi", "Wi", "C", "in_ld", "in_coff", "To", "Ho", "Wo", "out_ld", "out_coff",
-        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW")]
+        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "gate_nonpos")]
 
 
 class I3DConfig(Structure):

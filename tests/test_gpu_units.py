@@ -199,3 +199,39 @@ def test_maxpool_333_stride1_many_tiles_with_ties(thw, C):
                                   L.stream()))
     want = torch.where(xcl > 0, base + dxcl, torch.zeros_like(base))
     assert torch.allclose(acc, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,st,thw", [((1, 3, 3), (1, 2, 2), (3, 9, 10)), ((3, 3, 3), (1, 1, 1), (4, 9, 8)),
+                                      ((3, 3, 3), (2, 2, 2), (5, 8, 7)), ((2, 2, 2), (2, 2, 2), (4, 6, 6))])
+def test_maxpool_gate_nonpos_equals_relu_mask(k, st, thw):
+    """desc.gate_nonpos (dead windows recorded in the forward) gives the same input gradient as
+    the explicit ReLU gate on a post-ReLU input with many zeros."""
+    import ivf_arch as arch
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(11)
+    B, C = 2, 12
+    x = torch.relu(torch.randn((B, C) + thw, generator=gen) - 0.8)   # mostly zeros
+    pads = [arch.same_pad(n, kk, ss)[0] for n, kk, ss in zip(thw, k, st)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, st)]
+    gy = to_cl(torch.randn((B, C) + tuple(outs), generator=gen).cuda(), C)
+    xcl = to_cl(x.cuda(), C)
+    res = []
+    for flag in (0, 1):
+        d = L.PoolDesc()
+        d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, *thw, C, C, 0
+        d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *outs, C, 0
+        d.kT, d.kH, d.kW = k
+        d.sT, d.sH, d.sW = st
+        d.pT, d.pH, d.pW = pads
+        d.gate_nonpos = flag
+        y = torch.zeros((B,) + tuple(outs) + (C,), device='cuda')
+        idx = torch.zeros(y.shape, dtype=torch.uint8, device='cuda')
+        L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(y), L.ptr(idx), L.stream()))
+        dx = torch.full_like(xcl, float('nan'))
+        L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gy), L.ptr(idx), L.ptr(dx), None if flag else L.ptr(xcl),
+                                      0, L.stream()))
+        res.append((y, dx, idx))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert bool((res[1][2] == 255).any()) and not bool((res[0][2] == 255).any())
