@@ -572,6 +572,10 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   a.dbg = dbg;
   if (d->variant != IVF_CONV_AUTO) {
     // explicit kernel variant (set by the plan's tuner)
+    if (d->variant == IVF_CONV_PIX4) {
+      IVF_CHECK_ARG(d->math == 1 && conv_pix4_supported(a), "conv3d: pix4 variant needs split-bf16, 4-channel pixels, stride (1|2,2,2), k <= 7");
+      return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
+    }
     if (d->variant >= IVF_CONV_HALO_BASE) {
       IVF_CHECK_ARG(d->math == 1 && conv_halo_supported(a), "conv3d: halo variant needs split-bf16, stride 1, k in 2..4");
       return conv_halo_launch_variant(a, d->variant - IVF_CONV_HALO_BASE, (hipStream_t)stream);
@@ -579,6 +583,7 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     return conv_igemm_launch_variant(a, d->math, d->variant - IVF_CONV_IGEMM_BASE, (hipStream_t)stream);
   }
   if (d->math == 1 && !no_halo && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
+  if (d->math == 1 && !no_halo && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
 
@@ -673,8 +678,10 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   for (int v = 0; v < 3 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
   ConvKArgs a{};
   a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
+  a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.d2s = d->d2s; a.in2 = d->in2;
   if (d->math == 1 && conv_halo_supported(a))
     for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
+  if (d->math == 1 && conv_pix4_supported(a) && n < max_ids) ids[n++] = IVF_CONV_PIX4;
   return n;
 }
 

@@ -177,5 +177,7 @@ int conv_halo_supported(const ConvKArgs& a);
 int conv_halo_launch(ConvKArgs& a, hipStream_t s);
 int conv_halo_num_variants();
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s);
+int conv_pix4_supported(const ConvKArgs& a);
+int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s);
 
 }  // namespace ivf
