@@ -41,6 +41,8 @@ NCLASS = 48
 
 def variant_name(v):
     """kernel template instance behind a profiler class id (include/ivf_hip.h)"""
+    if v == 40:
+        return "conv3d_pix4_kernel"
     if v >= 16:
         name = _HALO[v - 16]
         return f"conv3d_halo_kernel<{name if name.count(',') == 5 else name + ',32'}>"

@@ -59,7 +59,8 @@ def _check_forward_backward(eng, tag, shape, g):
     assert rel_err(sample, ref) < 8e-2
     assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
-    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < 3e-2
+    # per-frame sums cancel to ~1e-6 of the gradient's norm: the most tie-sensitive figure here
+    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < (3e-2 if eng.math == "fp32" else 6e-2)
 
 
 def _modulewise_backward(eng, sd_np, shape, pool_kernel):
