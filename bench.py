@@ -34,18 +34,22 @@ PEAK_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
 _HALO = ["4,192,32,96,1", "4,128,64,64,1", "4,128,32,64,1", "4,96,32,96,1", "4,64,32,64,1", "4,64,64,64,2",
          "4,32,32,32,1", "4,32,64,32,2", "2,192,32,96,1", "2,128,32,64,1", "2,96,32,96,1", "2,64,32,64,1",
          "2,32,32,32,1", "2,64,64,64,2", "2,128,64,64,1", "4,64,32,64,2", "4,96,32,96,2", "4,32,32,32,2",
-         "2,192,32,96,1,16", "2,128,32,64,1,16", "4,96,32,96,1,16", "4,64,32,64,1,16", "2,96,32,96,1,16"]
+         "2,192,32,96,1,16", "2,128,32,64,1,16", "4,96,32,96,1,16", "4,64,32,64,1,16", "2,96,32,96,1,16",
+         "4,192,32,96,1,32,4,14", "4,128,32,64,1,32,4,14", "4,96,32,96,1,32,4,14", "4,64,32,64,1,32,4,14",
+         "4,32,32,32,1,32,4,14", "4,64,32,32,1,32,4,14", "4,32,32,32,2,32,4,14", "4,128,32,128,1,32,4,14"]
 _IGEMM = ["128,128,2,2", "128,64,4,1", "128,32,4,1"]
 NCLASS = 48
 
 
 def variant_name(v):
     """kernel template instance behind a profiler class id (include/ivf_hip.h)"""
-    if v == 40:
+    if v == 47:
         return "conv3d_pix4_kernel"
     if v >= 16:
         name = _HALO[v - 16]
-        return f"conv3d_halo_kernel<{name if name.count(',') == 5 else name + ',32'}>"
+        if name.count(',') == 4:
+            name += ',32'
+        return f"conv3d_halo_kernel<{name if name.count(',') == 7 else name + ',8,8'}>"
     if v >= 4:
         return f"conv3d_igemm_bf16x3_kernel<{_IGEMM[v - 4]}>"
     return f"conv3d_igemm_kernel<{_IGEMM[v - 1]}>"

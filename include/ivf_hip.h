@@ -132,7 +132,7 @@ typedef struct {
 #define IVF_CONV_AUTO 0
 #define IVF_CONV_IGEMM_BASE 1
 #define IVF_CONV_HALO_BASE 16
-#define IVF_CONV_PIX4 40 /* 4-channel-pixel strided kernel (the stem): split-bf16, Cin = in_ld = 4, stride (1|2, 2, 2), k <= 7 */
+#define IVF_CONV_PIX4 47 /* 4-channel-pixel strided kernel (the stem): split-bf16, Cin = in_ld = 4, stride (1|2, 2, 2), k <= 7 */
 int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_ids);
 
 /* out = epilogue(conv(in, w_packed)): v = acc*scale[n] + shift[n] (NULL = 1 / 0);

@@ -16,8 +16,6 @@
 
 namespace ivf {
 
-constexpr int TH = 8, TW = 8;
-
 // Position (h, w) inside the 8 x 8 plane of a tile for plane-row p in [0,64): two 32-row MFMA
 // tiles (4 h-rows x 8 w each).  Which lane bit feeds which coordinate bit is free as long as
 // the A operand and the epilogue agree; the choice per halo width minimises LDS bank conflicts
@@ -41,17 +39,34 @@ __device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
   *w = ww;
 }
 
+// Box row -> (t, h, w) inside a TT x TH x TW box.  8 x 8 planes use the permuted order above;
+// other plane shapes (4 x 14: the 28 x 28 and 14 x 14 maps of Mixed_3*/4*, which 8 x 8 boxes
+// cover with 23 % of their rows outside the map) use raster order.
+template <int TH, int TW>
+__device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, int* w) {
+  if constexpr (TH == 8 && TW == 8) {
+    tile_hw(row & 63, hw_pitch, h, w);
+    *t = row >> 6;
+  } else {
+    const int p = row % (TH * TW);
+    *t = row / (TH * TW);
+    *h = p / TW;
+    *w = p % TW;
+  }
+}
+
 // KS = 2 splits the taps of a chunk between two groups of waves (each wave then owns a
 // bigger output sub-tile, i.e. fewer LDS fragment reads per MFMA: what narrow outputs such as
 // the stem's 32-column backward-data need); the two partial sums meet in LDS at the end.
 // BKH = channels per chunk: 32, or 16 to halve the LDS footprint so that TWO workgroups are
 // resident per CU and one's halo staging / weight pipeline overlaps the other's MFMAs.
-template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH>
-__global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
+template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH, int TH, int TW>
+__global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
                                                                                                 int tilesT,
                                                                                                 int tilesH,
                                                                                                 int tilesW) {
   constexpr int BM = TT * TH * TW;
+  static_assert(BM % WROWS == 0 && WROWS % 32 == 0 && BN % WCOLS == 0 && WCOLS % 32 == 0, "tile");
   constexpr int WM = BM / WROWS, WN = BN / WCOLS;
   constexpr int NT = WM * WN * KS * 64;
   constexpr int TM = WROWS / 32, TN = WCOLS / 32;
@@ -93,9 +108,9 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int r = wm * WROWS + i * 32 + li;
-    int ph, pw;
-    tile_hw(r & 63, (a.dbg & 128) ? 0 : HW, &ph, &pw);
-    arow[i] = ((r >> 6) * HH + ph) * HW + pw;
+    int pt, ph, pw;
+    box_pos<TH, TW>(r, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+    arow[i] = (pt * HH + ph) * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
   const int nsteps = (ntaps + KS - 1) / KS;      // tap group g handles taps [g*nsteps, (g+1)*nsteps)
@@ -361,7 +376,7 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
   // backward-data): every lane quad holds one 16-byte pixel and a wave's direct stores land as
   // 32-byte pieces.  Park the tile in LDS as [2TT][16][16][4] and write whole 256-byte pixel
   // rows instead.
-  if (BN == 32 && a.d2s && a.Cout == 32 && a.bsT == 2 && a.bsH == 2 && a.bsW == 2 && !a.accumulate && !a.relu &&
+  if (TH == 8 && TW == 8 && BN == 32 && a.d2s && a.Cout == 32 && a.bsT == 2 && a.bsH == 2 && a.bsW == 2 && !a.accumulate && !a.relu &&
       a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && !(a.dbg & 1024)) {
     float* ot = reinterpret_cast<float*>(smem);
     if (wk == 0) {
@@ -404,22 +419,22 @@ __global__ __launch_bounds__((TT * 64 / WROWS) * (BN / WCOLS) * KS * 64) void co
   conv_epilogue<TM, TN>(
       a, acc,
       [&](int row) {
-        int ph, pw;
-        tile_hw(row & 63, (a.dbg & 128) ? 0 : HW, &ph, &pw);
-        int t = t0 + (row >> 6), h = h0 + ph, w = w0 + pw;
+        int pt, ph, pw;
+        box_pos<TH, TW>(row, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+        int t = t0 + pt, h = h0 + ph, w = w0 + pw;
         if (t >= a.To || h >= a.Ho || w >= a.Wo) return -1;
         return ((b * a.To + t) * a.Ho + h) * a.Wo + w;
       },
       wm * WROWS, n0 + wn * WCOLS, li, lh);
 }
 
-template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32>
+template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH = 8, int TW = 8>
 static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
-  constexpr int NT = (TT * 64 / WROWS) * (BN / WCOLS) * KS * 64;
+  constexpr int NT = (TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64;
   constexpr int ROWB = (BKH + 8) * 2;
   const int HR = (TT + a.kT - 1) * (TH + a.kH - 1) * (TW + a.kW - 1);
   const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
-  if (KS == 2 && (size_t)TT * 64 * BN * 4 > (size_t)2 * HR * ROWB) {
+  if (KS == 2 && (size_t)TT * TH * TW * BN * 4 > (size_t)2 * HR * ROWB) {
     set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
     return IVF_ERR_UNSUPPORTED;
   }
@@ -429,7 +444,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH>),
+    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -438,7 +453,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
   const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
-  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
+  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -461,7 +476,10 @@ int conv_halo_supported(const ConvKArgs& a) {
 // 16-channel chunks (two workgroups per CU):
 // 18: 2 192  32 x 96  1     19: 2 128  32 x 64  1    20: 4  96  32 x 96  1    21: 4  64  32 x 64  1
 // 22: 2  96  32 x 96  1
-int conv_halo_num_variants() { return 23; }
+// 4 x 4 x 14 boxes (224 rows = 7 MFMA row tiles; exact on 28- and 14-wide maps):
+// 23: 192  32 x 96  1     24: 128  32 x 64  1     25:  96  32 x 96  1     26:  64  32 x 64  1
+// 27:  32  32 x 32  1     28:  64  32 x 32  1     29:  32  32 x 32  2     30: 128  32 x 128 1
+int conv_halo_num_variants() { return 31; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -488,6 +506,14 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 20: return launch_halo<4, 96, 32, 96, 1, 16>(a, 20, s);
     case 21: return launch_halo<4, 64, 32, 64, 1, 16>(a, 21, s);
     case 22: return launch_halo<2, 96, 32, 96, 1, 16>(a, 22, s);
+    case 23: return launch_halo<4, 192, 32, 96, 1, 32, 4, 14>(a, 23, s);
+    case 24: return launch_halo<4, 128, 32, 64, 1, 32, 4, 14>(a, 24, s);
+    case 25: return launch_halo<4, 96, 32, 96, 1, 32, 4, 14>(a, 25, s);
+    case 26: return launch_halo<4, 64, 32, 64, 1, 32, 4, 14>(a, 26, s);
+    case 27: return launch_halo<4, 32, 32, 32, 1, 32, 4, 14>(a, 27, s);
+    case 28: return launch_halo<4, 64, 32, 32, 1, 32, 4, 14>(a, 28, s);
+    case 29: return launch_halo<4, 32, 32, 32, 2, 32, 4, 14>(a, 29, s);
+    case 30: return launch_halo<4, 128, 32, 128, 1, 32, 4, 14>(a, 30, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

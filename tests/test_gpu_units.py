@@ -149,7 +149,8 @@ def test_maxpool_fwd_bwd(name, golden):
     L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(ycl), L.ptr(idx), L.stream()))
     assert np.array_equal(from_cl(ycl, C).cpu().numpy(), g[f'pool_{name}_y'])   # bit-exact
     dxcl = torch.full_like(xcl, float('nan'))
-    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy, cp)), L.ptr(idx), L.ptr(dxcl), None, 0,
+    gycl = to_cl(gy, cp)
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(dxcl), None, 0,
                                   L.stream()))
     dx = from_cl(dxcl, C).cpu().numpy()
     ref = g[f'pool_{name}_dx']
@@ -186,7 +187,8 @@ def test_maxpool_333_stride1_many_tiles_with_ties(thw, C):
     L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(ycl), L.ptr(idx), L.stream()))
     assert np.array_equal(from_cl(ycl, C).cpu().numpy(), y.detach().numpy())
     dxcl = torch.full_like(xcl, float('nan'))
-    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy.cuda(), C)), L.ptr(idx), L.ptr(dxcl), None, 0,
+    gycl = to_cl(gy.cuda(), C)
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(dxcl), None, 0,
                                   L.stream()))
     dx = from_cl(dxcl, C).cpu().numpy()
     ref = xr.grad.numpy()
@@ -195,7 +197,7 @@ def test_maxpool_333_stride1_many_tiles_with_ties(thw, C):
     # accumulate + ReLU gate path
     base = torch.randn_like(xcl)
     acc = base.clone()
-    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(to_cl(gy.cuda(), C)), L.ptr(idx), L.ptr(acc), L.ptr(xcl), 1,
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(acc), L.ptr(xcl), 1,
                                   L.stream()))
     want = torch.where(xcl > 0, base + dxcl, torch.zeros_like(base))
     assert torch.allclose(acc, want, rtol=1e-6, atol=1e-6)
@@ -235,3 +237,61 @@ def test_maxpool_gate_nonpos_equals_relu_mask(k, st, thw):
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     assert bool((res[1][2] == 255).any()) and not bool((res[0][2] == 255).any())
+
+
+@pytest.mark.parametrize("k,cin,cout,thw", [(3, 32, 40, (5, 15, 30)), (3, 16, 200, (3, 9, 15)), (4, 8, 32, (4, 9, 10)),
+                                            (1, 24, 72, (2, 5, 7))])
+def test_every_conv_variant_matches_torch(k, cin, cout, thw):
+    """Every kernel variant the tuner may pick (ivf_conv3d_variants: implicit GEMM tiles, all
+    LDS-halo boxes) computes the same convolution: compared with torch's fp64 conv3d on
+    ragged sizes (partial boxes in every dimension, partial channel tiles), with the fused
+    scale/shift + ReLU epilogue and with the accumulate + ReLU-gate epilogue."""
+    import torch.nn.functional as F
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn((B, cin) + thw, generator=gen)
+    w = torch.randn(cout, cin, k, k, k, generator=gen) * 0.1
+    scale = torch.rand(cout, generator=gen) + 0.5
+    shift = torch.randn(cout, generator=gen) * 0.1
+    pf, pb = (k - 1) // 2, k - 1 - (k - 1) // 2
+    ref = F.conv3d(F.pad(x.double(), (pf, pb, pf, pb, pf, pb)), w.double())
+    ref_relu = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1))
+    mm = L.MATH_MODES["bf16x3"]
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, k, k, k, mm), device='cuda')
+    wd, scd, shd = w.cuda(), scale.cuda(), shift.cuda()   # (kept alive: L.ptr only takes the address)
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, cin, cin, k, k, k, mm, L.stream()))
+    xcl = to_cl(x.cuda())
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cin, cin, 0
+    d.To, d.Ho, d.Wo = thw
+    d.Cout, d.out_ld, d.out_coff = cout, cout, 0
+    d.kT = d.kH = d.kW = k
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = pf
+    d.math = mm
+    d.mask_ld, d.mask_coff = cout, 0
+    ids = (ctypes.c_int * 64)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    assert n >= 3
+    base = torch.randn((B,) + thw + (cout,), generator=gen).cuda()
+    gate = (torch.rand((B,) + thw + (cout,), generator=gen) > 0.3).float().cuda()
+    want_acc = (base.double().cpu() + ref.permute(0, 2, 3, 4, 1)) * gate.double().cpu()
+    ran = 0
+    for v in list(ids)[:n]:
+        d.variant = v
+        d.relu, d.accumulate = 1, 0
+        y = torch.full((B,) + thw + (cout,), float('nan'), device='cuda')
+        rc = lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), L.ptr(scd), L.ptr(shd), None, L.ptr(y), L.stream())
+        if rc != 0:
+            continue   # variant not applicable to this shape (LDS budget)
+        ran += 1
+        got = from_cl(y, cout).double().cpu()
+        assert rel_err(got.numpy(), ref_relu.numpy()) < 1e-4, f"variant {v}"
+        d.relu, d.accumulate = 0, 1
+        acc = base.clone()
+        L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), None, None, L.ptr(gate), L.ptr(acc), L.stream()))
+        assert rel_err(acc.double().cpu().numpy(), want_acc.numpy()) < 1e-4, f"variant {v} (accumulate)"
+    assert ran >= 3

@@ -4,9 +4,11 @@ sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import torch, ivf_lib as L
 lib = L.lib()
 # Mixed_3c.b1b-like: B=32 clips, [8,28,28], Cin=128 -> Cout=192, 3x3x3
-B, T, H, W, cin, cout = 32, 8, 28, 28, 128, 192
+B, T, H, W, cin, cout = int(os.environ.get('IVF_B', '32')), 8, 28, 28, 128, 192
+if len(sys.argv) > 1 and sys.argv[1] == '4f':
+    B, T, H, W, cin, cout = int(os.environ.get('IVF_B', '32')), 4, 14, 14, 160, 320
 if len(sys.argv) > 1 and sys.argv[1] == '2c':
-    B, T, H, W, cin, cout = 32, 8, 56, 56, 64, 192
+    B, T, H, W, cin, cout = int(os.environ.get('IVF_B', '32')), 8, 56, 56, 64, 192
 x = torch.randn(B, T, H, W, cin, device='cuda')
 w = torch.randn(cout, cin, 3, 3, 3, device='cuda') * 0.05
 wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, 3, 3, 3, 1), device='cuda')
