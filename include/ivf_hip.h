@@ -91,6 +91,17 @@ int ivf_search_step(float* raw_mask, const float* sig, const float* dscore_dsig,
 
 int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream);
 
+/* Clip ingest: the arithmetic of ImLoader.__getitem__ /
+ * KTHImLoader.__getitem__ after the JPEG decode (data_loader_jpg.py:29-37,
+ * data_loader_kth.py:25-44): uint8 frames [B][T][H][W][C] -> float32 (exact), permuted to
+ * [B][C][T][H][W] (layout IVF_INGEST_NCTHW, the tensor the reference hands to the model) or
+ * to channels-last rows of cpad >= C floats with zero pad lanes (IVF_INGEST_CL, the plan's
+ * input layout).  The host uploads a quarter of the bytes of the fp32 clip. */
+#define IVF_INGEST_NCTHW 0
+#define IVF_INGEST_CL 1
+int ivf_clip_ingest_u8(const unsigned char* frames, float* out, int B, int T, int H, int W, int C, int layout,
+                       int cpad, ivf_stream_t stream);
+
 /* ------------------------------------------------------------------ Unit3D */
 
 /* Arithmetic of the implicit-GEMM convolution:

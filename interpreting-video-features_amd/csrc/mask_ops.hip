@@ -553,6 +553,66 @@ extern "C" int ivf_search_step(float* raw_mask, const float* sig, const float* d
   return IVF_OK;
 }
 
+// uint8 [B][T][H][W][C] -> fp32 NCTHW or channels-last (cpad).  One thread per 4 consecutive
+// pixels of a row: 4*C bytes in (dword loads when aligned), 16-byte stores out.
+__global__ void clip_ingest_kernel(const unsigned char* __restrict__ f, float* __restrict__ out, int B, int T,
+                                   int HW, int C, int layout, int cpad) {
+  const size_t quads_per_frame = (size_t)(HW + 3) / 4;
+  const size_t total = (size_t)B * T * quads_per_frame;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t fr = i / quads_per_frame;          // b*T + t
+    const int px = (int)(i - fr * quads_per_frame) * 4;
+    const int np = min(4, HW - px);
+    const int b = (int)(fr / T), t = (int)(fr - (size_t)b * T);
+    const unsigned char* src = f + (fr * HW + px) * C;
+    float v[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[p][c] = 0.f;
+    if (C == 3 && np == 4 && (reinterpret_cast<size_t>(src) & 3) == 0) {
+      const uint3 w = *reinterpret_cast<const uint3*>(src);
+      const unsigned wd[3] = {w.x, w.y, w.z};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k / 3][k % 3] = (float)((wd[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    } else {
+      for (int p = 0; p < np; ++p)
+        for (int c = 0; c < C && c < 4; ++c) v[p][c] = (float)src[p * C + c];
+    }
+    if (layout == IVF_INGEST_NCTHW) {
+      for (int c = 0; c < C; ++c) {
+        float* dst = out + (((size_t)b * C + c) * T + t) * HW + px;
+        if (np == 4 && (reinterpret_cast<size_t>(dst) & 15) == 0)
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        else
+          for (int p = 0; p < np; ++p) dst[p] = v[p][c];
+      }
+    } else {
+      for (int p = 0; p < np; ++p) {
+        float* dst = out + (fr * HW + px + p) * cpad;
+        if (cpad == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
+        } else {
+          for (int c = 0; c < cpad; ++c) dst[c] = c < C ? v[p][c] : 0.f;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int ivf_clip_ingest_u8(const unsigned char* frames, float* out, int B, int T, int H, int W, int C,
+                                  int layout, int cpad, ivf_stream_t stream) {
+  IVF_CHECK_ARG(frames && out, "clip_ingest: null pointer");
+  IVF_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, "clip_ingest: bad dims (1 <= C <= 4)");
+  IVF_CHECK_ARG(layout == IVF_INGEST_NCTHW || (layout == IVF_INGEST_CL && cpad >= C),
+                "clip_ingest: layout must be NCTHW or channels-last with cpad >= C");
+  const size_t total = (size_t)B * T * (((size_t)H * W + 3) / 4);
+  hipLaunchKernelGGL(clip_ingest_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, out, B, T,
+                     H * W, C, layout, cpad);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
 extern "C" int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream) {
   IVF_CHECK_ARG(x && y && n > 0, "sigmoid: bad args");
   hipLaunchKernelGGL(sigmoid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);

@@ -1,0 +1,54 @@
+"""Clip ingest on the device.
+
+The reference decodes `frame%02d.jpg` files with PIL and converts the stacked uint8 frames
+to a float32 [3,T,H,W] tensor on the host (data_loader_jpg.py:23-41,
+data_loader_kth.py:20-43); the model then receives 4 bytes per sample over PCIe.  Here the
+decoded uint8 frames are uploaded as they are and `ivf_clip_ingest_u8` does the cast and
+the permute on the GPU (bit-exact: every uint8 is representable).
+"""
+import os
+
+import numpy as np
+import torch
+
+import ivf_lib as L
+
+NCTHW, CHANNELS_LAST = 0, 1
+
+
+def decode_clip_u8(folder, clip_size, pattern="frame{:02d}.jpg"):
+    """Host side of ImLoader/KTHImLoader.__getitem__: decode `clip_size` frames of a clip
+    folder (frames are numbered from 1) -> uint8 [T,H,W,3]."""
+    from PIL import Image
+    imgs = []
+    for i in range(clip_size):
+        im = Image.open(os.path.join(folder, pattern.format(i + 1)))
+        arr = np.frombuffer(im.tobytes(), dtype=np.uint8)
+        imgs.append(arr.reshape((im.size[1], im.size[0], 3)))
+    return np.array(imgs)
+
+
+def ingest_u8(frames, layout=NCTHW, cpad=4, out=None):
+    """uint8 frames [T,H,W,C] or [B,T,H,W,C] (numpy, CPU or CUDA tensor) -> float32 device
+    tensor [B,C,T,H,W] (NCTHW) or [B,T,H,W,cpad] (CHANNELS_LAST).  An unbatched input gives
+    an unbatched result, like the reference's __getitem__."""
+    L.require_gpu()
+    t = torch.as_tensor(frames)
+    if t.dtype != torch.uint8:
+        raise TypeError("ingest_u8 expects uint8 frames")
+    unbatched = t.dim() == 4
+    if unbatched:
+        t = t[None]
+    if t.dim() != 5:
+        raise ValueError("frames must be [T,H,W,C] or [B,T,H,W,C]")
+    if not t.is_cuda:
+        t = t.contiguous().pin_memory().cuda(non_blocking=True)
+    t = t.contiguous()
+    B, T, H, W, C = t.shape
+    shape = (B, C, T, H, W) if layout == NCTHW else (B, T, H, W, cpad)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous float32 tensor of shape {shape}")
+    L.check(L.lib().ivf_clip_ingest_u8(L.ptr(t), L.ptr(out), B, T, H, W, C, layout, cpad, L.stream()))
+    return out[0] if unbatched else out

@@ -69,6 +69,7 @@ _SIGS = {
     "ivf_adam_step": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P]),
     "ivf_search_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P]),
     "ivf_sigmoid": (c_int, [_P, _P, _I, _P]),
+    "ivf_clip_ingest_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ivf_conv3d": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ivf_bn_fold": (c_int, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "ivf_conv3d_pack_fwd_elems": (c_size_t, [_I] * 6),

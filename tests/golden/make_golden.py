@@ -366,8 +366,53 @@ def gen_search():
     save('search', **out)
 
 
+def gen_ingest():
+    """Clip ingest: the reference loader classes on small synthetic JPEG
+    folders.  The fixture holds the JPEG bytes themselves (a few KB) and the loader output."""
+    import io
+    import tempfile
+    from PIL import Image
+    import data_loader_kth as ref_kth
+    import data_loader_jpg as ref_jpg
+    T, H, W = 5, 12, 18
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, '0'))
+        jpgs = []
+        for i in range(T):
+            arr = R.uniform(f'g/ingest/frame{i}', (H, W, 3), 0, 255).astype(np.uint8)
+            buf = io.BytesIO()
+            Image.fromarray(arr, 'RGB').save(buf, format='JPEG', quality=92)
+            jpgs.append(np.frombuffer(buf.getvalue(), dtype=np.uint8))
+            with open(os.path.join(root, '0', 'frame{:02d}.jpg'.format(i + 1)), 'wb') as f:
+                f.write(buf.getvalue())
+        with open(os.path.join(root, '0', 'class.txt'), 'w') as f:
+            f.write('3')
+        with open(os.path.join(root, '0', 'label.txt'), 'w') as f:
+            f.write('person01_boxing_d1')
+        ds = ref_kth.KTHImLoader(root, clip_size=T, get_item_id=True)
+        data, label, tag = ds[0]
+        out['kth_data'] = data.numpy()
+        out['kth_label'] = np.array(label)
+        out['kth_tag'] = np.array(tag)
+        # smth loader: same arithmetic behind PicDatabase; drive __getitem__ with a stub item list
+        ds2 = ref_jpg.ImLoader.__new__(ref_jpg.ImLoader)
+        ds2.clip_size, ds2.get_item_id = T, True
+        from data_parser import ListData
+        it = ListData('17', '2', os.path.join(root, '0'))
+        ds2.path_data = [it]
+        d2, l2, id2 = ds2[0]
+        out['smth_data'] = d2.numpy()
+        out['smth_label'] = np.array(l2)
+        out['smth_id'] = np.array(id2)
+    for i, j in enumerate(jpgs):
+        out[f'jpeg{i}'] = j
+    out['shape'] = np.array([T, H, W])
+    save('ingest', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search']
+    which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

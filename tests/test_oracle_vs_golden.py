@@ -7,7 +7,7 @@ import torch
 
 import ivf_recipe as R
 from conftest import rel_err
-from oracle import clstm_ref, gradcam_ref, i3d_ref, mask_ref
+from oracle import clstm_ref, gradcam_ref, i3d_ref, ingest_ref, mask_ref
 
 torch.set_num_threads(8)
 
@@ -149,3 +149,17 @@ def test_i3d_search_first_iterations_match_reference(golden):
         return i3d_ref.forward(v, sd)[0, target]
     res = mask_ref.search_clip(x, score_fn, 0.01, 0.02, 2, 'freeze', init=torch.from_numpy(g['s16_init']))
     assert np.max(np.abs(res['traj'].numpy() - g['s16_traj'][:2]) / np.abs(g['s16_traj'][:2])) < 1e-4
+
+
+def test_ingest_matches_reference_loaders(golden):
+    """the oracle's decode + cast + permute equals what the reference's
+    ImLoader / KTHImLoader returned for the same JPEG bytes."""
+    g = golden('ingest')
+    T = int(g['shape'][0])
+    frames = ingest_ref.decode_frames([g[f'jpeg{i}'] for i in range(T)])
+    assert frames.dtype == np.uint8 and frames.shape == (T, int(g['shape'][1]), int(g['shape'][2]), 3)
+    x = ingest_ref.to_model_input(frames)
+    assert x.dtype == np.float32
+    assert np.array_equal(x, g['kth_data']) and np.array_equal(x, g['smth_data'])
+    cl = ingest_ref.to_channels_last(frames, 4)
+    assert np.array_equal(cl[..., :3].transpose(3, 0, 1, 2), x) and not cl[..., 3].any()
