@@ -134,6 +134,96 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
   }
 }
 
+// backward for the strided pools with the window geometry known at compile time: at most
+// ceil(k/s) outputs per dimension cover an input cell (2 x 2 for the 1x3x3 / (1,2,2) pools),
+// so every candidate's (dY, arg-max) load is issued up front, unconditionally predicated --
+// no dependent loops, neighbouring cells' re-reads come from L1.  One thread per input cell
+// and 4 channels; contributions are added in ascending (to, ho, wo) order like everywhere else.
+template <int KT, int KH, int KW, int ST, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const float* __restrict__ dy,
+                                                                const unsigned char* __restrict__ idx,
+                                                                float* __restrict__ dx,
+                                                                const float* __restrict__ relu_mask, int accumulate,
+                                                                PoolArgs a) {
+  constexpr int NT = (KT + ST - 1) / ST, NH = (KH + SH - 1) / SH, NW = (KW + SW - 1) / SW;
+  const int C4 = a.C >> 2;
+  const size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * C4;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c4 = (int)(i % C4);
+  const size_t m = i / C4;
+  const int wi = (int)(m % a.Wi);
+  const size_t t1 = m / a.Wi;
+  const int hi = (int)(t1 % a.Hi);
+  const size_t t2 = t1 / a.Hi;
+  const int ti = (int)(t2 % a.Ti);
+  const int b = (int)(t2 / a.Ti);
+  const int nt = ti + a.pT, nh = hi + a.pH, nw = wi + a.pW;
+  float4 g[NT][NH][NW];
+  unsigned u[NT][NH][NW];
+  // candidate j along a dim: output o = n/s - (N-1-j) (ascending in j), tap k = n - o*s
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int to = nt / ST - (NT - 1 - jt), kt = nt - to * ST;
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) {
+      const int ho = nh / SH - (NH - 1 - jh), kh = nh - ho * SH;
+#pragma unroll
+      for (int jw = 0; jw < NW; ++jw) {
+        const int wo = nw / SW - (NW - 1 - jw), kw = nw - wo * SW;
+        const bool ok = to >= 0 && to < a.To && kt < KT && ho >= 0 && ho < a.Ho && kh < KH && wo >= 0 &&
+                        wo < a.Wo && kw < KW;
+        g[jt][jh][jw] = make_float4(0.f, 0.f, 0.f, 0.f);
+        u[jt][jh][jw] = 0xffffffffu;
+        if (ok) {
+          const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+          g[jt][jh][jw] = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + 4 * c4);
+          // compare against this cell's tap: store (recorded tap XOR own tap), zero byte = match
+          const unsigned tap = (unsigned)((kt * KH + kh) * KW + kw);
+          u[jt][jh][jw] = *reinterpret_cast<const unsigned*>(idx + mo * a.C + 4 * c4) ^ (tap * 0x01010101u);
+        }
+      }
+    }
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh)
+#pragma unroll
+      for (int jw = 0; jw < NW; ++jw) {
+        const unsigned x = u[jt][jh][jw];
+        const float4 v = g[jt][jh][jw];
+        if ((x & 0x000000ffu) == 0u) acc[0] += v.x;
+        if ((x & 0x0000ff00u) == 0u) acc[1] += v.y;
+        if ((x & 0x00ff0000u) == 0u) acc[2] += v.z;
+        if ((x & 0xff000000u) == 0u) acc[3] += v.w;
+      }
+  float* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
+  if (accumulate) {
+    float4 o = *reinterpret_cast<const float4*>(dst);
+    acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+  }
+  if (relu_mask) {
+    float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
+    if (!(k.x > 0.f)) acc[0] = 0.f;
+    if (!(k.y > 0.f)) acc[1] = 0.f;
+    if (!(k.z > 0.f)) acc[2] = 0.f;
+    if (!(k.w > 0.f)) acc[3] = 0.f;
+  }
+  *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+template <int KT, int KH, int KW, int ST, int SH, int SW>
+static bool launch_pool_bwd_fixed(const PoolArgs& a, const float* dy, const unsigned char* idx, float* dx,
+                                  const float* relu_mask, int accumulate, hipStream_t s) {
+  if (a.kT != KT || a.kH != KH || a.kW != KW || a.sT != ST || a.sH != SH || a.sW != SW) return false;
+  const size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4);
+  hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<KT, KH, KW, ST, SH, SW>), dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, s, dy, idx, dx, relu_mask, accumulate, a);
+  return true;
+}
+
 // ---------------------------------------------------------------- LDS-tiled max-pool
 // The direct kernels above re-read every input (forward) or every (dY, arg-max) pair
 // (backward) once per window that covers it -- up to 27x through L1/L2.  The tiled forms
@@ -858,6 +948,19 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
                        (hipStream_t)stream, dy, argmax, dx, relu_mask, accumulate, a, G, slabs);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
+  }
+  // the strided pools of the I3D variants (I3D_doubled.py:272-300; temporal strides 1 or 2)
+  static const bool no_fixed = getenv("IVF_POOL_NO_FIXED") != nullptr;
+  if (!direct && !no_fixed && (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4) / 256 < 0x7fffffffu) {
+    hipStream_t hs = (hipStream_t)stream;
+    if (launch_pool_bwd_fixed<1, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<3, 3, 3, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<3, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<2, 2, 2, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<2, 2, 2, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs)) {
+      IVF_CHECK_LAUNCH();
+      return IVF_OK;
+    }
   }
   // measured (16-channel slabs): the tiled gather wins 1.3-1.6x for every pool of the net
   if (!direct && shm <= 80 * 1024) {

@@ -295,3 +295,48 @@ def test_every_conv_variant_matches_torch(k, cin, cout, thw):
         L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), None, None, L.ptr(gate), L.ptr(acc), L.stream()))
         assert rel_err(acc.double().cpu().numpy(), want_acc.numpy()) < 1e-4, f"variant {v} (accumulate)"
     assert ran >= 3
+
+
+@pytest.mark.parametrize("k,st,thw", [((1, 3, 3), (1, 2, 2), (3, 17, 20)), ((3, 3, 3), (2, 2, 2), (5, 15, 14)),
+                                      ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 2, 2), (4, 15, 9)),
+                                      ((2, 2, 2), (1, 2, 2), (4, 8, 7)), ((2, 2, 2), (2, 2, 2), (3, 7, 7))])
+def test_strided_maxpool_with_ties_matches_torch(k, st, thw):
+    """Strided pools (fixed-geometry backward kernels) against torch's CPU max_pool3d over the
+    zero-padded input (TF-'same' padding, I3D_doubled.py:8-40) on tie-rich inputs."""
+    import torch.nn.functional as F
+    import ivf_arch as arch
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(9)
+    B, C = 2, 40
+    x = torch.relu(torch.round(torch.randn((B, C) + thw, generator=gen) * 3) / 3)
+    pads = [arch.same_pad(n, kk, ss) for n, kk, ss in zip(thw, k, st)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, st)]
+    gy = torch.randn((B, C) + tuple(outs), generator=gen)
+    xr = x.clone().requires_grad_()
+    y = F.max_pool3d(F.pad(xr, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1])), k, st)
+    assert list(y.shape[2:]) == outs
+    y.backward(gy)
+    xcl = to_cl(x.cuda(), C)
+    ycl = torch.zeros((B,) + tuple(outs) + (C,), device='cuda')
+    idx = torch.zeros(ycl.shape, dtype=torch.uint8, device='cuda')
+    d = L.PoolDesc()
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, *thw, C, C, 0
+    d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *outs, C, 0
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = st
+    d.pT, d.pH, d.pW = [p[0] for p in pads]
+    L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xcl), L.ptr(ycl), L.ptr(idx), L.stream()))
+    assert np.array_equal(from_cl(ycl, C).cpu().numpy(), y.detach().numpy())
+    gycl = to_cl(gy.cuda(), C)
+    dxcl = torch.full_like(xcl, float('nan'))
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(dxcl), None, 0, L.stream()))
+    dx = from_cl(dxcl, C).cpu().numpy()
+    ref = xr.grad.numpy()
+    assert np.array_equal(dx != 0, ref != 0)
+    assert np.allclose(dx, ref, rtol=1e-5, atol=1e-6)
+    base = torch.randn_like(xcl)
+    acc = base.clone()
+    L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(acc), L.ptr(xcl), 1, L.stream()))
+    want = torch.where(xcl > 0, base + dxcl, torch.zeros_like(base))
+    assert torch.allclose(acc, want, rtol=1e-6, atol=1e-6)

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import torch, ivf_lib as L
 lib = L.lib()
-cases = {'3c.b3a': (64, 8, 28, 28, 480, (3,3,3), (1,1,1)), '2a': (64, 8, 112, 112, 64, (1,3,3), (1,2,2)),
+cases = {'3c.b3a': (64, 8, 28, 28, 480, (3,3,3), (1,1,1)), '2a': (64, 8, 112, 112, 64, (1,3,3), (1,2,2)), '3a': (64, 8, 56, 56, 192, (1,3,3), (1,2,2)), '4a': (64, 8, 28, 28, 480, (3,3,3), (2,2,2)),
          '4f.b3a': (64, 4, 14, 14, 528, (3,3,3), (1,1,1))}
 import ivf_arch as arch
 for name, (B, T, H, W, C, k, s) in cases.items():
@@ -26,4 +26,4 @@ for name, (B, T, H, W, C, k, s) in cases.items():
         for _ in range(10): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        print(f"{name:8s} {label} {ms*1e3:8.1f} us  {bytes_/ms/1e9:6.2f} TB/s (compulsory bytes)   no_s1={os.environ.get('IVF_POOL_NO_S1','')}")
+        print(f"{name:8s} {label} {ms*1e3:8.1f} us  {bytes_/ms/1e9:6.2f} TB/s (compulsory bytes)   no_fixed={os.environ.get('IVF_POOL_NO_FIXED','')}")
