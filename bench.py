@@ -50,6 +50,8 @@ def variant_name(v):
         if name.count(',') == 4:
             name += ',32'
         return f"conv3d_halo_kernel<{name if name.count(',') == 7 else name + ',8,8'}>"
+    if v >= 7:
+        return f"conv3d_igemm_bf16x3_kernel<{['128,256,4,1', '128,192,4,1', '128,160,4,1'][v - 7]}>"
     if v >= 4:
         return f"conv3d_igemm_bf16x3_kernel<{_IGEMM[v - 4]}>"
     return f"conv3d_igemm_kernel<{_IGEMM[v - 1]}>"

@@ -460,8 +460,17 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
-  const bool timed = prof_begin(s, IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0));
-  if (math == 0)
+  // profiler class: 1..3 fp32 tiles, 4..6 split-bf16 tiles, 7..9 the wide split-bf16 tiles
+  const int cls = BN > 128 ? (BN == 256 ? 7 : (BN == 192 ? 8 : 9))
+                           : IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0);
+  const bool timed = prof_begin(s, cls);
+  if constexpr (BN > 128) {
+    if (math == 0) {
+      set_error("conv3d: wide implicit-GEMM tiles exist for split-bf16 only");
+      return IVF_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  } else if (math == 0)
     hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
@@ -483,6 +492,11 @@ int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s) {
     case 0: return launch_variant<128, 128, 2, 2>(a, math, s);
     case 1: return launch_variant<128, 64, 4, 1>(a, math, s);
     case 2: return launch_variant<128, 32, 4, 1>(a, math, s);
+    // wide tiles for the 1x1x1 convs (HBM-bound: the input rows are read once instead of once
+    // per 64-column tile)
+    case 3: return launch_variant<128, 256, 4, 1>(a, math, s);
+    case 4: return launch_variant<128, 192, 4, 1>(a, math, s);
+    case 5: return launch_variant<128, 160, 4, 1>(a, math, s);
   }
   set_error("conv3d: unknown implicit-GEMM variant %d", v);
   return IVF_ERR_BAD_ARG;
@@ -676,6 +690,8 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   if (!d || !ids) return 0;
   int n = 0;
   for (int v = 0; v < 3 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
+  if (d->math == 1 && d->kT * d->kH * d->kW == 1)
+    for (int v = 3; v < 6 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
   ConvKArgs a{};
   a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
   a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.d2s = d->d2s; a.in2 = d->in2;
