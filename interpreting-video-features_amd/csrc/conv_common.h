@@ -148,24 +148,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      float old[16], gate[16];
-      int mrow[16];
       const int rbase = row_base + i * 32 + 4 * lh;
+      // two batches of 8 rows: enough loads in flight, half the live registers of one batch of 16
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow[r] = rowmap(rbase + (r & 3) + 8 * (r >> 2));
-        const bool ok = nvalid && m >= 0;
-        old[r] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
-        gate[r] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
-      }
+      for (int half = 0; half < 2; ++half) {
+        float old[8], gate[8];
+        int mrow[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow[r];
-        if (!nvalid || m < 0) continue;
-        float v = acc[i][j][r] * sc + sh + old[r];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        if (!(gate[r] > 0.f)) v = 0.f;
-        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+        for (int q = 0; q < 8; ++q) {
+          const int r = half * 8 + q;
+          const int m = mrow[q] = rowmap(rbase + (r & 3) + 8 * (r >> 2));
+          const bool ok = nvalid && m >= 0;
+          old[q] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
+          gate[q] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = mrow[q];
+          if (!nvalid || m < 0) continue;
+          float v = acc[i][j][half * 8 + q] * sc + sh + old[q];
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          if (!(gate[q] > 0.f)) v = 0.f;
+          a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+        }
       }
     }
   }
