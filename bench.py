@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (searched together)")
+    ap.add_argument("--batch", type=int, default=128, help="clips per GPU per step (searched together)")
     ap.add_argument("--iters", type=int, default=300, help="Adam iterations per search (reference N=300)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")

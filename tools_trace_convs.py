@@ -36,7 +36,7 @@ assert len(seq) == len(kern), (len(seq), len(kern))
 tot = totf = pool_t = 0; out = []
 for s, k in zip(seq, kern):
     dur = (k[2] - k[1]) / 1e3; fl = s[2] * B
-    var = (('H' if 'halo' in k[0] else '') + k[0].split('<')[1].split('>')[0].replace(' ', '')) if '<' in k[0] else 'pool'
+    var = (('H' if 'halo' in k[0] else '') + k[0].split('<')[1].split('>')[0].replace(' ', '')) if '<' in k[0] else ('pix4' if 'pix4' in k[0] else 'pool')
     out.append((dur, s[0], s[1], var, k[3] // 256, fl / dur / 1e6 if fl else 0, s[3] * B, s[4], s[5]))
     if fl: tot += dur; totf += fl
     else: pool_t += dur
@@ -44,4 +44,4 @@ print("conv us %.0f  TF %.1f   pools us %.0f   iteration us %.0f" % (tot, totf /
 cum = 0
 for o in sorted(out, reverse=True)[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
     cum += o[0]
-    print("%8.1f us %s %-20s %-14s wgs=%-6d %6.1f TF  M=%d Cout=%d K=%d  cum %.0f" % (o + (cum,)))
+    print("%8.1f us %s %-20s %-22s wgs=%-6d %6.1f TF  M=%d Cout=%d K=%d  cum %.0f" % (o + (cum,)))
