@@ -50,6 +50,8 @@ def variant_name(v):
         if name.count(',') == 4:
             name += ',32'
         return f"conv3d_halo_kernel<{name if name.count(',') == 7 else name + ',8,8'}>"
+    if v in (10, 11):
+        return f"conv3d_igemm_bf16x3_kernel<{'64,64,2,2' if v == 10 else '64,128,2,2'}>"
     if v >= 7:
         return f"conv3d_igemm_bf16x3_kernel<{['128,256,4,1', '128,192,4,1', '128,160,4,1'][v - 7]}>"
     if v >= 4:

@@ -461,10 +461,11 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
   // profiler class: 1..3 fp32 tiles, 4..6 split-bf16 tiles, 7..9 the wide split-bf16 tiles
-  const int cls = BN > 128 ? (BN == 256 ? 7 : (BN == 192 ? 8 : 9))
-                           : IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0);
+  const int cls = BM == 64 ? (BN == 64 ? 10 : 11)
+                  : BN > 128 ? (BN == 256 ? 7 : (BN == 192 ? 8 : 9))
+                             : IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0);
   const bool timed = prof_begin(s, cls);
-  if constexpr (BN > 128) {
+  if constexpr (BN > 128 || BM == 64) {
     if (math == 0) {
       set_error("conv3d: wide implicit-GEMM tiles exist for split-bf16 only");
       return IVF_ERR_UNSUPPORTED;
@@ -497,6 +498,9 @@ int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s) {
     case 3: return launch_variant<128, 256, 4, 1>(a, math, s);
     case 4: return launch_variant<128, 192, 4, 1>(a, math, s);
     case 5: return launch_variant<128, 160, 4, 1>(a, math, s);
+    // small tiles: twice the workgroups per CU for the latency-bound short-K GEMMs
+    case 6: return launch_variant<64, 64, 2, 2>(a, math, s);
+    case 7: return launch_variant<64, 128, 2, 2>(a, math, s);
   }
   set_error("conv3d: unknown implicit-GEMM variant %d", v);
   return IVF_ERR_BAD_ARG;
@@ -691,7 +695,7 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   int n = 0;
   for (int v = 0; v < 3 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
   if (d->math == 1 && d->kT * d->kH * d->kW == 1)
-    for (int v = 3; v < 6 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
+    for (int v = 3; v < 8 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
   ConvKArgs a{};
   a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
   a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.d2s = d->d2s; a.in2 = d->in2;
