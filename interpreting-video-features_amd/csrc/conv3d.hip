@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   const int m0 = mt * BM;
   const int n0 = nt * BN;
 
-  const int g = tid & 7;     // A: float4 group of the 32-wide chunk
-  const int r0 = tid >> 3;   //    rows r0 + 32 j
-  const int g2 = tid & 3;    // B: group of 8 bf16
-  const int q0 = tid >> 2;   //    rows q0 + 64 j
+  const int g = tid & 7;            // A: float4 group of the 32-wide chunk
+  const int r0 = perm8(tid >> 3);   //    rows r0 + 32 j (perm8: conflict-free LDS staging writes)
+  const int g2 = tid & 3;           // B: group of 8 bf16
+  const int q0 = perm8(tid >> 2);   //    rows q0 + 64 j
 
   int a_base[AROWS], a_t0[AROWS], a_h0[AROWS], a_w0[AROWS];
 #pragma unroll

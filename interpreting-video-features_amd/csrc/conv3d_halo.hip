@@ -145,7 +145,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       int idx = tid + q * NT;
       int grp = idx / (BN * G8);
       int rem = idx - grp * (BN * G8);
-      int row = rem / G8, g2 = rem % G8;
+      int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
       int tap = step + grp * nsteps;
       int n = n0 + row;
       int c = c0 + 8 * g2;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       int idx = tid + q * NT;
       int grp = idx / (BN * G8);
       int rem = idx - grp * (BN * G8);
-      int row = rem / G8, g2 = rem % G8;
+      int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
       if (grp < KS) {
         unsigned char* bh = b_base + (size_t)(buf * KS + grp) * 2 * BN * ROWB;
         unsigned char* bl = bh + (size_t)BN * ROWB;
@@ -265,7 +265,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   constexpr int HRMAX = (TT + 3) * (TH + 3) * (TW + 3);
   constexpr int NSTG = ASYNC ? (HRMAX * G4 + NT - 1) / NT : 4;
   float4 stg[NSTG];
-  const int ngroups = HR * G4;
+  // (rows are visited in perm8 order, so the item range is padded to whole blocks of 8 rows)
+  const int ngroups = BKH == 32 ? ((HR + 7) & ~7) * G4 : HR * G4;
   int stage_base = 0;
   auto stage_load = [&](int c0) {
 #pragma unroll
@@ -273,9 +274,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       int idx = stage_base + u * NT + tid;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < ngroups) {
-        int row = idx / G4, g = idx % G4;
+        int row = BKH == 32 ? perm8(idx / G4) : idx / G4, g = idx % G4;
+        if (row >= HR) row = -1;
         int c = c0 + 4 * g;
-        int pos = rowoff[row];
+        int pos = row >= 0 ? rowoff[row] : -1;
         if (pos >= 0 && c < a.Cin && !(a.dbg & 512))
           v = *reinterpret_cast<const float4*>(a.in + (size_t)pos * a.in_ld + a.in_coff + c);
       }
@@ -286,8 +288,9 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
       int idx = stage_base + u * NT + tid;
-      if (idx < ngroups) {
-        int dst = (idx / G4) * ROWB + 8 * (idx % G4);
+      const int srow = BKH == 32 ? perm8(idx / G4) : idx / G4;
+      if (idx < ngroups && srow < HR) {
+        int dst = srow * ROWB + 8 * (idx % G4);
         uint2 h, l;
         split4(stg[u], &h, &l);
         *reinterpret_cast<uint2*>(a_hi + dst) = h;

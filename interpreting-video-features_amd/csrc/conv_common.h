@@ -65,6 +65,13 @@ __device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
   *lo = make_uint2(pk_bf16(v.x - hx, v.y - hy), pk_bf16(v.z - hz, v.w - hw));
 }
 
+// Staging writes put 8 (A, 8-byte pieces) or 4 (weights, 16-byte pieces) lanes on one 80-byte LDS
+// row; with consecutive rows on consecutive lane groups the rows of one LDS write group sit
+// 80 B apart and overlap in banks (2-way: ~30 % of all LDS cycles of these kernels were
+// conflict cycles).  Handing lane group i the row perm8(i) puts rows 4 apart (320 B = 64 mod
+// 128) into each write group instead: disjoint banks.  Bijective on every aligned block of 8.
+__device__ __forceinline__ int perm8(int r) { return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3); }
+
 // Epilogue shared by both arithmetic variants.  Lane holds column n = li of each 32x32 tile,
 // rows (r&3) + 8*(r>>2) + 4*lh.  Per tile all old-value / gate loads are issued before any
 // store (the accumulate path reads and writes the same buffer, which would otherwise
