@@ -83,7 +83,7 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
   // weight ring: thread -> (plane, row, 8-value piece) of the 64 x 32 step tile
   constexpr int PF = 3;
   uint2 rb[PF][2];
-  const int bpl = tid >> 8, brow = (tid & 255) >> 2, bg = tid & 3;
+  const int bpl = tid >> 8, brow = perm8((tid & 255) >> 2), bg = tid & 3;   // perm8: conflict-free 16-byte LDS writes
   auto load_b = [&](int slot, int step) {
     const int n = ld_n0 + brow, k0 = 8 * bg;
     uint2 v0 = make_uint2(0u, 0u), v1 = v0;
