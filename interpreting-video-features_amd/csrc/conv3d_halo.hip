@@ -39,12 +39,26 @@ __device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
   *w = ww;
 }
 
-// Box row -> (t, h, w) inside a TT x TH x TW box.  8 x 8 planes use the permuted order above;
-// other plane shapes (4 x 14: the 28 x 28 and 14 x 14 maps of Mixed_3*/4*, which 8 x 8 boxes
-// cover with 23 % of their rows outside the map) use raster order.
-template <int TH, int TW>
+// Box row -> (t, h, w) inside a TT x TH x TW box.
+//  * 4 x 8 x 8 boxes: a 32-row MFMA tile is one h-row of the box across its 4 planes (4 t x 8 w).
+//    The halo plane stride of a 3x3x3 conv is 100 rows = 4 (mod 16), so the four planes' 8-row runs
+//    start at 16-byte bank slots 0, 4, 8, 12 of the 256-byte LDS bank row: putting planes {0,2} on
+//    one ds_read_b128 lane group ({0-3,12-15,20-27}, MI355X_MICROARCH.md) and {1,3} on the other
+//    makes the A-fragment reads conflict-free (the earlier one-plane tiles could not be: one slot
+//    is hit three times by any 4 h x 8 w cell set at row pitch 10).  For k = 2 and 4 this order is
+//    as good as the old one (2-way).
+//  * other 8 x 8 boxes (TT = 2) keep the permuted one-plane order above;
+//  * other plane shapes (4 x 14: the 28 x 28 and 14 x 14 maps of Mixed_3*/4*, which 8 x 8 boxes
+//    cover with 23 % of their rows outside the map) use raster order.
+template <int TT, int TH, int TW>
 __device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, int* w) {
-  if constexpr (TH == 8 && TW == 8) {
+  if constexpr (TT == 4 && TH == 8 && TW == 8) {
+    const int li = row & 31, q = li >> 2, ql = q & 3;
+    const int sel = ((ql + 1) >> 1) & 1;
+    *t = (q >> 2) ? 3 - sel : sel;
+    *w = (ql >> 1) * 4 + (li & 3);
+    *h = row >> 5;
+  } else if constexpr (TH == 8 && TW == 8) {
     tile_hw(row & 63, hw_pitch, h, w);
     *t = row >> 6;
   } else {
@@ -109,7 +123,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   for (int i = 0; i < TM; ++i) {
     int r = wm * WROWS + i * 32 + li;
     int pt, ph, pw;
-    box_pos<TH, TW>(r, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+    box_pos<TT, TH, TW>(r, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
     arow[i] = (pt * HH + ph) * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
@@ -391,9 +405,9 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int bh, bw;
-          tile_hw(row & 63, (a.dbg & 128) ? 0 : HW, &bh, &bw);
-          const int tt2 = 2 * (row >> 6) + pt, hh2 = 2 * bh + ph, ww2 = 2 * bw + pw;
+          int bt, bh, bw;
+          box_pos<TT, TH, TW>(row, (a.dbg & 128) ? 0 : HW, &bt, &bh, &bw);
+          const int tt2 = 2 * bt + pt, hh2 = 2 * bh + ph, ww2 = 2 * bw + pw;
           ot[((tt2 * 16 + hh2) * 16 + ww2) * 4 + c] = acc[i][0][r];
         }
     }
@@ -423,7 +437,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       a, acc,
       [&](int row) {
         int pt, ph, pw;
-        box_pos<TH, TW>(row, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+        box_pos<TT, TH, TW>(row, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
         int t = t0 + pt, h = h0 + ph, w = w0 + pw;
         if (t >= a.To || h >= a.Ho || w >= a.Wo) return -1;
         return ((b * a.To + t) * a.Ho + h) * a.Wo + w;
