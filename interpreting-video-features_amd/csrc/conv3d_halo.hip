@@ -69,6 +69,16 @@ __device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, i
   }
 }
 
+// LDS rows per halo plane.  The 4 x 8 x 8 boxes want the plane stride = 4 (mod 8) rows (see
+// box_pos): 100 for k = 3 as it is, 121 -> 124 for k = 4, 81 -> 84 for k = 2 (pad rows are
+// never staged nor read).
+template <int TT, int TH, int TW>
+__host__ __device__ inline int halo_plane_rows(int HH, int HW) {
+  int ps = HH * HW;
+  if (TT == 4 && TH == 8 && TW == 8) ps += (4 - ps % 8 + 8) % 8;
+  return ps;
+}
+
 // KS = 2 splits the taps of a chunk between two groups of waves (each wave then owns a
 // bigger output sub-tile, i.e. fewer LDS fragment reads per MFMA: what narrow outputs such as
 // the stem's 32-column backward-data need); the two partial sums meet in LDS at the end.
@@ -91,7 +101,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HT = TT + a.kT - 1, HH = TH + a.kH - 1, HW = TW + a.kW - 1;
-  const int HR = HT * HH * HW;
+  const int PS = halo_plane_rows<TT, TH, TW>(HH, HW);   // LDS rows per halo plane (>= HH * HW)
+  const int HR = HT * PS;
   unsigned char* a_hi = smem;
   unsigned char* a_lo = smem + (size_t)HR * ROWB;
   unsigned char* b_base = smem + (size_t)2 * HR * ROWB;   // [2 buffers][hi, lo][BN rows]
@@ -124,19 +135,19 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     int r = wm * WROWS + i * 32 + li;
     int pt, ph, pw;
     box_pos<TT, TH, TW>(r, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
-    arow[i] = (pt * HH + ph) * HW + pw;
+    arow[i] = pt * PS + ph * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
   const int nsteps = (ntaps + KS - 1) / KS;      // tap group g handles taps [g*nsteps, (g+1)*nsteps)
   const int khw = a.kH * a.kW;
   // halo row -> input position (decoded once; the chunk loop only adds the channel offset)
   for (int row = tid; row < HR; row += NT) {
-    int hw = row % HW;
-    int r2 = row / HW;
-    int hh = r2 % HH;
-    int ht = r2 / HH;
+    int ht = row / PS;
+    int rem = row - ht * PS;
+    int hh = rem / HW;
+    int hw = rem - hh * HW;
     int ti = t0 - a.pT + ht, hi = h0 - a.pH + hh, wi = w0 - a.pW + hw;
-    bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+    bool ok = hh < HH && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
     rowoff[row] = ok ? ((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi : -1;
   }
 
@@ -199,7 +210,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     const int rem = tap - kt * khw;
     const int kh = rem / a.kW;
     const int kw = rem - kh * a.kW;
-    return ((kt * HH + kh) * HW + kw) * ROWB;
+    return (kt * PS + kh * HW + kw) * ROWB;
   };
   auto load_a = [&](int step) {
     const int tap = step + wk * nsteps;
@@ -449,7 +460,7 @@ template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH
 static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int NT = (TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64;
   constexpr int ROWB = (BKH + 8) * 2;
-  const int HR = (TT + a.kT - 1) * (TH + a.kH - 1) * (TW + a.kW - 1);
+  const int HR = (TT + a.kT - 1) * halo_plane_rows<TT, TH, TW>(TH + a.kH - 1, TW + a.kW - 1);
   const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
   if (KS == 2 && (size_t)TT * TH * TW * BN * 4 > (size_t)2 * HR * ROWB) {
     set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
