@@ -255,6 +255,67 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
   }
 }
 
+// The same sums for the reference geometry (k = 5, stride 2, pad 2, even H and W;
+// convolution_lstm.py:23-31), one thread per 2 x 2 block of input pixels: a gate position
+// reaches pixel parity (py, px) through tap (2j + py, 2i + px), so the 3 x 3 gate positions
+// around the block are loaded once (16 gates each) and fan out to the four pixels with
+// compile-time taps -- no parity branches (the per-pixel form above diverges on every tap) and
+// 36 instead of 100 gate loads per pixel.  Sums run in the same (ky, kx, o) order per pixel.
+__global__ __launch_bounds__(256) void clstm_xconv_bwd_k5s2_kernel(
+    const float* __restrict__ dG, const float* __restrict__ wB, float* __restrict__ dx, int B, int T, int Cin,
+    int H, int W, long sB, long sC, long sT, int hid, int Ho, int Wo) {
+  const int G = 4 * hid;
+  const long plane = (long)Ho * Wo;
+  const int Hb = H >> 1, Wb = W >> 1;
+  const long total = (long)B * T * Hb * Wb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int bx = i % Wb;
+    const int by = (i / Wb) % Hb;
+    const int t = (i / ((long)Wb * Hb)) % T;
+    const int b = i / ((long)Wb * Hb * T);
+    float acc[2][2][4];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[py][px][c] = 0.f;
+    const float* gp = dG + (((long)b * T + t) * G) * plane;
+    // tap order per pixel must stay ascending in (ky, kx): j (hence yo) descends as ky ascends
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int yo = by + 1 - j;
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii) {
+        const int xo = bx + 1 - ii;
+        float g[16];
+        const bool ok = yo >= 0 && yo < Ho && xo >= 0 && xo < Wo;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) g[o] = (ok && o < G) ? gp[(long)o * plane + (long)yo * Wo + xo] : 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          if (2 * j + py > 4) continue;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            if (2 * ii + px > 4) continue;
+            const float* wp = wB + ((2 * j + py) * 5 + (2 * ii + px)) * 64;
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[py][px][c] += wp[o * 4 + c] * g[o];
+          }
+        }
+      }
+    }
+    for (int c = 0; c < Cin; ++c)
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float* dst = dx + b * sB + c * sC + t * sT + (long)(2 * by + py) * W + 2 * bx;
+        *reinterpret_cast<float2*>(dst) = make_float2(acc[py][0][c], acc[py][1][c]);
+      }
+  }
+}
+
 // raw [G][cin][k][k] -> fwd table [cin][k][k][16] and bwd table [k][k][16][4] (zero padded)
 __global__ void clstm_weight_tables_kernel(const float* __restrict__ w, float* __restrict__ wT,
                                            float* __restrict__ wB, int G, int cin, int k) {
@@ -592,9 +653,15 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
       out = n->wsf(q.dX_off);
       sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
     }
-    hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384)), dim3(256), 0, s,
-                       n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
-                       c.stride, p.Ho, p.Wo);
+    if (k == 5 && c.stride == 2 && p.Hin % 2 == 0 && p.Win % 2 == 0 && hid <= 4 && sC % 2 == 0 && sT % 2 == 0 &&
+        sB % 2 == 0)
+      hipLaunchKernelGGL(clstm_xconv_bwd_k5s2_kernel, dim3(grid_for((long)b * T * (p.Hin / 2) * (p.Win / 2), 256, 16384)),
+                         dim3(256), 0, s, n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC,
+                         sT, hid, p.Ho, p.Wo);
+    else
+      hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384)), dim3(256), 0,
+                         s, n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
+                         c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
   }
   return IVF_OK;
