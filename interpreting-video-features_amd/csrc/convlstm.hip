@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
 // around the block are loaded once (16 gates each) and fan out to the four pixels with
 // compile-time taps -- no parity branches (the per-pixel form above diverges on every tap) and
 // 36 instead of 100 gate loads per pixel.  Sums run in the same (ky, kx, o) order per pixel.
+template <int CIN>   // input channels (1..4) at compile time: only the live accumulators are computed
 __global__ __launch_bounds__(256) void clstm_xconv_bwd_k5s2_kernel(
-    const float* __restrict__ dG, const float* __restrict__ wB, float* __restrict__ dx, int B, int T, int Cin,
+    const float* __restrict__ dG, const float* __restrict__ wB, float* __restrict__ dx, int B, int T, int,
     int H, int W, long sB, long sC, long sT, int hid, int Ho, int Wo) {
   const int G = 4 * hid;
   const long plane = (long)Ho * Wo;
@@ -273,13 +274,13 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_k5s2_kernel(
     const int by = (i / Wb) % Hb;
     const int t = (i / ((long)Wb * Hb)) % T;
     const int b = i / ((long)Wb * Hb * T);
-    float acc[2][2][4];
+    float acc[2][2][CIN];
 #pragma unroll
     for (int py = 0; py < 2; ++py)
 #pragma unroll
       for (int px = 0; px < 2; ++px)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[py][px][c] = 0.f;
+        for (int c = 0; c < CIN; ++c) acc[py][px][c] = 0.f;
     const float* gp = dG + (((long)b * T + t) * G) * plane;
     // tap order per pixel must stay ascending in (ky, kx): j (hence yo) descends as ky ascends
 #pragma unroll
@@ -302,12 +303,13 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_k5s2_kernel(
 #pragma unroll
             for (int o = 0; o < 16; ++o)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[py][px][c] += wp[o * 4 + c] * g[o];
+              for (int c = 0; c < CIN; ++c) acc[py][px][c] += wp[o * 4 + c] * g[o];
           }
         }
       }
     }
-    for (int c = 0; c < Cin; ++c)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
         float* dst = dx + b * sB + c * sC + t * sT + (long)(2 * by + py) * W + 2 * bx;
@@ -653,11 +655,21 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
       out = n->wsf(q.dX_off);
       sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
     }
-    if (k == 5 && c.stride == 2 && p.Hin % 2 == 0 && p.Win % 2 == 0 && hid <= 4 && sC % 2 == 0 && sT % 2 == 0 &&
-        sB % 2 == 0)
-      hipLaunchKernelGGL(clstm_xconv_bwd_k5s2_kernel, dim3(grid_for((long)b * T * (p.Hin / 2) * (p.Win / 2), 256, 16384)),
-                         dim3(256), 0, s, n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC,
-                         sT, hid, p.Ho, p.Wo);
+    if (k == 5 && c.stride == 2 && p.Hin % 2 == 0 && p.Win % 2 == 0 && hid <= 4 && p.cin <= 4 && sC % 2 == 0 &&
+        sT % 2 == 0 && sB % 2 == 0)
+    {
+      const dim3 grid(grid_for((long)b * T * (p.Hin / 2) * (p.Win / 2), 256, 16384));
+#define IVF_XB(CI)                                                                                              \
+  hipLaunchKernelGGL(clstm_xconv_bwd_k5s2_kernel<CI>, grid, dim3(256), 0, s, n->wsf(p.dG_off), n->wa + p.wxB_off, \
+                     out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, p.Ho, p.Wo)
+      switch (p.cin) {
+        case 1: IVF_XB(1); break;
+        case 2: IVF_XB(2); break;
+        case 3: IVF_XB(3); break;
+        default: IVF_XB(4); break;
+      }
+#undef IVF_XB
+    }
     else
       hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384)), dim3(256), 0,
                          s, n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
