@@ -17,6 +17,8 @@
 #include <cstring>
 #include <vector>
 
+#include <cstdlib>
+
 #include "ivf_common.h"
 
 namespace ivf {
@@ -118,6 +120,72 @@ __global__ __launch_bounds__(256) void clstm_step_fwd_kernel(
   }
 }
 
+// The same cell step with the hidden-state convolution split over the 4 waves of a workgroup by
+// input channel (hid <= 4): a workgroup owns 64 pixels, wave c accumulates the 25 taps of channel c
+// into all 16 gates (its weights stay wave-uniform scalar operands), the partial sums meet in LDS
+// and wave j finishes hidden channel j.  A quarter of the serial chain per thread: what the small
+// maps of the second layer (75 workgroups in the one-thread-per-pixel form) are bound by.
+__global__ __launch_bounds__(256) void clstm_step_fwd_split_kernel(
+    const float* __restrict__ gx, const float* __restrict__ whT, float* __restrict__ S, float* __restrict__ Hs,
+    int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = 4 * hid;
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  const long i = (long)blockIdx.x * 64 + lane;
+  const bool live = i < total;
+  const int xo = live ? (int)(i % Wo) : 0;
+  const int yo = live ? (int)((i / Wo) % Ho) : 0;
+  const int b = live ? (int)(i / plane) : 0;
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+  if (w == 0 && live) {
+    const float* gp = gx + (((long)b * T + t) * G) * plane + (long)yo * Wo + xo;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = (o < G) ? gp[(long)o * plane] : 0.f;
+  }
+  if (t > 0 && w < hid && live) {
+    const float* hp = Hs + ((((long)b * T + (t - 1)) * hid) + w) * plane;
+    for (int ky = 0; ky < k; ++ky) {
+      int y = yo - pad + ky;
+      for (int kx = 0; kx < k; ++kx) {
+        int xx = xo - pad + kx;
+        float v = ((unsigned)y < (unsigned)Ho && (unsigned)xx < (unsigned)Wo) ? hp[(long)y * Wo + xx] : 0.f;
+        const float* wp = whT + ((w * k + ky) * k + kx) * 16;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 16; ++o) red[w][o][lane] = acc[o];
+  __syncthreads();
+  const int j = w;
+  if (j >= hid || !live) return;
+  float a[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int o = g * hid + j;
+    a[g] = ((red[0][o][lane] + red[1][o][lane]) + red[2][o][lane]) + red[3][o][lane];
+  }
+  const long px = (long)yo * Wo + xo;
+  float* sp = S + (((long)b * T + t) * 5 * hid) * plane + px;
+  float ci = sigmoidf_(a[0]), cf = sigmoidf_(a[1]), cg = tanhf(a[2]), co = sigmoidf_(a[3]);
+  float cp = (t > 0) ? S[((((long)b * T + (t - 1)) * 5 + 4) * hid + j) * plane + px] : 0.f;
+  float cc = cf * cp + ci * cg;
+  float ch = co * tanhf(cc);
+  sp[(long)(0 * hid + j) * plane] = ci;
+  sp[(long)(1 * hid + j) * plane] = cf;
+  sp[(long)(2 * hid + j) * plane] = cg;
+  sp[(long)(3 * hid + j) * plane] = co;
+  sp[(long)(4 * hid + j) * plane] = cc;
+  Hs[(((long)b * T + t) * hid + j) * plane + px] = ch;
+}
+
 // X[b,t,j,yp,xp] = max over 2x2 of (scale[j]*H + shift[j]); first strict maximum wins
 __global__ void clstm_bnpool_fwd_kernel(const float* __restrict__ Hs, const float* __restrict__ scale,
                                         const float* __restrict__ shift, float* __restrict__ X,
@@ -215,6 +283,68 @@ __global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
       dcp[(long)j * plane] = dcc * cf;
     }
   }
+}
+
+// Backward cell step split over the 4 waves of a workgroup by gate type (hid <= 4): wave g gathers
+// the taps of gates [g*hid, (g+1)*hid) of step t+1 into a partial dH (weights stay scalar operands),
+// the partials meet in LDS, wave j finishes hidden channel j.  Same reasoning as the forward split.
+__global__ __launch_bounds__(256) void clstm_step_bwd_split_kernel(
+    const float* __restrict__ dHpool, const float* __restrict__ whB, const float* __restrict__ S,
+    float* __restrict__ dG, float* __restrict__ dC, int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = 4 * hid;
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  const long i = (long)blockIdx.x * 64 + lane;
+  const bool live = i < total;
+  const int x = live ? (int)(i % Wo) : 0;
+  const int y = live ? (int)((i / Wo) % Ho) : 0;
+  const int b = live ? (int)(i / plane) : 0;
+  float dh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t + 1 < T && live) {
+    const float* gp = dG + (((long)b * T + (t + 1)) * G) * plane;
+    for (int ky = 0; ky < k; ++ky) {
+      int yy = y - ky + pad;
+      for (int kx = 0; kx < k; ++kx) {
+        int xx = x - kx + pad;
+        const bool ok = (unsigned)yy < (unsigned)Ho && (unsigned)xx < (unsigned)Wo;
+        const float* wp = whB + (ky * k + kx) * 64;     // [o][j], j padded to 4
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = w * hid + q;
+          float g = (ok && q < hid) ? gp[(long)o * plane + (long)yy * Wo + xx] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dh[j] += wp[o * 4 + j] * g;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[w][j][lane] = dh[j];
+  __syncthreads();
+  const int j = w;
+  if (j >= hid || !live) return;
+  const long px = (long)y * Wo + x;
+  const float dhj = dHpool[(((long)b * T + t) * hid + j) * plane + px] +
+                    (((red[0][j][lane] + red[1][j][lane]) + red[2][j][lane]) + red[3][j][lane]);
+  const float* sp = S + (((long)b * T + t) * 5 * hid) * plane + px;
+  float* gout = dG + (((long)b * T + t) * G) * plane + px;
+  float* dcp = dC + ((long)b * hid) * plane + px;
+  float ci = sp[(long)(0 * hid + j) * plane], cf = sp[(long)(1 * hid + j) * plane];
+  float cg = sp[(long)(2 * hid + j) * plane], co = sp[(long)(3 * hid + j) * plane];
+  float cc = sp[(long)(4 * hid + j) * plane];
+  float cp = (t > 0) ? S[((((long)b * T + (t - 1)) * 5 + 4) * hid + j) * plane + px] : 0.f;
+  float th = tanhf(cc);
+  float dco = dhj * th;
+  float dcc = dhj * co * (1.f - th * th) + ((t + 1 < T) ? dcp[(long)j * plane] : 0.f);
+  gout[(long)(0 * hid + j) * plane] = dcc * cg * (ci * (1.f - ci));
+  gout[(long)(1 * hid + j) * plane] = dcc * cp * (cf * (1.f - cf));
+  gout[(long)(2 * hid + j) * plane] = dcc * ci * (1.f - cg * cg);
+  gout[(long)(3 * hid + j) * plane] = dco * (co * (1.f - co));
+  dcp[(long)j * plane] = dcc * cf;
 }
 
 // dx[b,c,t,y,x] = sum_{o,ky,kx} Wx[o][c][ky][kx] * dG[b,t,o,(y+p-ky)/s,(x+p-kx)/s]  (exact divisions only)
@@ -591,9 +721,15 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
                        hid, k, c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
     for (int t = 0; t < T; ++t) {
-      hipLaunchKernelGGL(clstm_step_fwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
-                         s, n->wsf(p.gx_off), n->wa + p.whT_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
-                         p.Ho, p.Wo);
+      static const int split_below = getenv("IVF_CLSTM_SPLIT") ? atoi(getenv("IVF_CLSTM_SPLIT")) : (1 << 30);
+      if (hid <= 4 && (long)b * p.Ho * p.Wo <= split_below)
+        hipLaunchKernelGGL(clstm_step_fwd_split_kernel, dim3((unsigned)(((long)b * p.Ho * p.Wo + 63) / 64)), dim3(256), 0,
+                           s, n->wsf(p.gx_off), n->wa + p.whT_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
+                           p.Ho, p.Wo);
+      else
+        hipLaunchKernelGGL(clstm_step_fwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
+                           s, n->wsf(p.gx_off), n->wa + p.whT_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T, t, hid, k,
+                           p.Ho, p.Wo);
       IVF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(clstm_bnpool_fwd_kernel, dim3(grid_for((long)b * T * hid * p.Hp * p.Wp)), dim3(256), 0, s,
@@ -640,9 +776,15 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
                        p.Ho, p.Wo, p.Hp, p.Wp);
     IVF_CHECK_LAUNCH();
     for (int t = T - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(clstm_step_bwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
-                         s, n->wsf(p.dHp_off), n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off),
-                         n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
+      static const int split_below = getenv("IVF_CLSTM_SPLIT") ? atoi(getenv("IVF_CLSTM_SPLIT")) : (1 << 30);
+      if (hid <= 4 && (long)b * p.Ho * p.Wo <= split_below)
+        hipLaunchKernelGGL(clstm_step_bwd_split_kernel, dim3((unsigned)(((long)b * p.Ho * p.Wo + 63) / 64)), dim3(256), 0,
+                           s, n->wsf(p.dHp_off), n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off),
+                           n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
+      else
+        hipLaunchKernelGGL(clstm_step_bwd_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384)), dim3(256), 0,
+                           s, n->wsf(p.dHp_off), n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off),
+                           n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
       IVF_CHECK_LAUNCH();
     }
     float* out;
