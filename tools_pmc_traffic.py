@@ -38,12 +38,16 @@ def main():
     fetch, write = per_kernel(fa, "FETCH_SIZE"), per_kernel(fb, "WRITE_SIZE")
     kernels = {}
     for k in fetch:
-        if k not in write or fetch[k][1] != write[k][1]:
+        if k not in write:
             continue
-        n = fetch[k][1]
-        fkb, wkb = fetch[k][0] / n, write[k][0] / n
-        kernels[k] = {"launches": n, "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024),
+        # the tuner may give a small layer to a different variant in the two passes: per-pass averages,
+        # flagged when the launch counts (hence the layer mix) differ
+        nf, nw = fetch[k][1], write[k][1]
+        fkb, wkb = fetch[k][0] / nf, write[k][0] / nw
+        kernels[k] = {"launches": nf, "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024),
                       "fetch_kb_raw_per_launch": int(fkb), "write_kb_per_launch": int(wkb)}
+        if nf != nw:
+            kernels[k]["launches_write_pass"] = nw
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kernels.values())
     doc = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
                   "command (split-bf16); launches from the first search iteration on (after autotune); "
