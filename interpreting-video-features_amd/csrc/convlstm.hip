@@ -30,6 +30,8 @@ constexpr int MAXK = 7;
 // Weight tables are pre-transposed to [c][ky][kx][16 gate-channels] (and [ky][kx][16][4] for the
 // backward kernels): the index is wave-uniform, so the compiler fetches the 16 weights of a
 // tap with one scalar load and the FMAs take them as SGPR operands -- no LDS traffic at all.
+// The tap sums use fused multiply-adds (explicit fmaf: the file is built with -ffp-contract=off): these
+// kernels are VALU-bound and the unfused form costs twice the instructions; parity gates are 1e-3.
 __global__ __launch_bounds__(256) void clstm_xconv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
     float* __restrict__ gx, int B, int T, int Cin, int H, int W, long sB, long sC, long sT, int hid, int k,
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void clstm_xconv_fwd_kernel(
           float v = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? xp[(long)y * W + xx] : 0.f;
           const float* wp = wT + ((c * k + ky) * k + kx) * 16;
 #pragma unroll
-          for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
+          for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(wp[o], v, acc[o]);
         }
       }
     }
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void clstm_step_fwd_kernel(
                           ? hp[(long)c * plane + (long)y * Wo + xx] : 0.f;
             const float* wp = whT + ((c * k + ky) * k + kx) * 16;
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
+            for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(wp[o], v, acc[o]);
           }
         }
     }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void clstm_step_fwd_split_kernel(
         float v = ((unsigned)y < (unsigned)Ho && (unsigned)xx < (unsigned)Wo) ? hp[(long)y * Wo + xx] : 0.f;
         const float* wp = whT + ((w * k + ky) * k + kx) * 16;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] += wp[o] * v;
+        for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(wp[o], v, acc[o]);
       }
     }
   }
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void clstm_step_bwd_kernel(
           for (int o = 0; o < 16; ++o) {
             float g = (ok && o < G) ? gp[(long)o * plane + (long)yy * Wo + xx] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dh[j] += wp[o * 4 + j] * g;
+            for (int j = 0; j < 4; ++j) dh[j] = __builtin_fmaf(wp[o * 4 + j], g, dh[j]);
           }
         }
       }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void clstm_step_bwd_split_kernel(
           const int o = w * hid + q;
           float g = (ok && q < hid) ? gp[(long)o * plane + (long)yy * Wo + xx] : 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dh[j] += wp[o * 4 + j] * g;
+          for (int j = 0; j < 4; ++j) dh[j] = __builtin_fmaf(wp[o * 4 + j], g, dh[j]);
         }
       }
     }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_kernel(
         for (int o = 0; o < 16; ++o) {
           float g = (o < G) ? gp[(long)o * plane + (long)yo * Wo + xo] : 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] += wp[o * 4 + c] * g;
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_fmaf(wp[o * 4 + c], g, acc[c]);
         }
       }
     }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void clstm_xconv_bwd_k5s2_kernel(
 #pragma unroll
             for (int o = 0; o < 16; ++o)
 #pragma unroll
-              for (int c = 0; c < CIN; ++c) acc[py][px][c] += wp[o * 4 + c] * g[o];
+              for (int c = 0; c < CIN; ++c) acc[py][px][c] = __builtin_fmaf(wp[o * 4 + c], g[o], acc[py][px][c]);
           }
         }
       }
