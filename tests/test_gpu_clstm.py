@@ -81,3 +81,31 @@ def test_clstm_dropin_model(golden):
     assert rel_err(y.detach().cpu().numpy(), g['c3_probs']) < 1e-3
     (y[0, 2] + y[1, 4]).backward()
     assert rel_err(x.grad.cpu().numpy().ravel()[g['c3_dx_idx']], g['c3_dx_val']) < 2e-3
+
+
+@pytest.mark.parametrize("C,T,H,W,hidden,kernel,stride", [(2, 6, 24, 32, 3, 3, 2), (1, 5, 16, 24, 4, 5, 1),
+                                                          (3, 4, 18, 26, 2, 3, 1)])
+def test_clstm_other_geometries_match_oracle(C, T, H, W, hidden, kernel, stride):
+    """Geometries off the reference's (k 5, stride 2, hidden 4): the generic x-conv backward and the
+    hidden < 4 forms of the wave-split cell steps, against the CPU oracle (forward and dL/dx)."""
+    import ivf_engine
+    import ivf_recipe as R
+    from oracle import clstm_ref
+    layers, B, K = 2, 2, 5
+    sd_np = R.clstm_state_dict(num_classes=K, hidden=hidden, channels=C, kernel=kernel, layers=layers,
+                               image_size=(W, H), conv_stride=stride, tag=f'clstm_g{C}{hidden}{kernel}{stride}')
+    eng = ivf_engine.CLSTMEngine(K, (C, T, H, W), max_batch=B, hidden=hidden, layers=layers, kernel=kernel,
+                                 stride=stride, softmax=True)
+    eng.load_state_dict(sd_np)
+    x = torch.from_numpy(np.stack([R.clip(7 + i, C, T, H, W) for i in range(B)]) / 255.0).float()
+    sd = R.to_torch(sd_np)
+    xr = x.clone().requires_grad_()
+    y = clstm_ref.forward(xr, sd, layers=layers, hidden=hidden, kernel=kernel, stride=stride, steps=T,
+                          effective_step=(T - 1,), add_softmax=True)
+    y[0, 1].backward(retain_graph=True)
+    g0 = xr.grad.clone()
+    probs = eng.forward(x.cuda())
+    assert rel_err(probs.cpu().numpy(), y.detach().numpy()) < 1e-3
+    s, dx = eng.backward(B, target=[1, 2])
+    assert abs(float(s[0]) - float(y[0, 1].detach())) < 1e-5
+    assert rel_err(dx[0].cpu().numpy(), g0[0].numpy()) < 2e-3
