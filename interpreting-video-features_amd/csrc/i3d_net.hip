@@ -840,7 +840,8 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
         if (hipEventSynchronize(e1) != hipSuccess) { rc = IVF_ERR_HIP; set_error("autotune: sync failed"); break; }
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) { best = ms; best_id = ids[k]; }
+        // a later candidate must win by 1.5 %: keeps the choice between tied tile shapes stable from run to run
+        if (ms < best * (best_id == IVF_CONV_AUTO ? 1.f : 0.985f)) { best = ms; best_id = ids[k]; }
       }
       *slot = best_id;
     }
