@@ -69,6 +69,19 @@ int ivf_submask_pairs(const float* mask, int T, float thresh, int* run, int* par
 int ivf_reverse_fwd(const float* x, const int* partner, const float* weight, float* p, int B, int C,
                     int T, int HW, int out_cpad, ivf_stream_t stream);
 
+/* The same for b clips with per-clip masks [B,T] (partner/weight rows [B,T]); forward writes
+ * NCTHW (out_cpad 0) or 16-byte channels-last pixels (out_cpad 4). */
+int ivf_submask_pairs_batched(const float* mask, int B, int T, float thresh, int* partner, float* weight,
+                              ivf_stream_t stream);
+int ivf_reverse_fwd_batched(const float* x, const int* partner, const float* weight, float* p, int B, int C,
+                            int T, int HW, int out_cpad, ivf_stream_t stream);
+/* Autograd of mask.py:49-56 w.r.t. the mask (the reference optimises through 'reverse' when
+ * temporalMaskType == 'reverse', smth:121,202): for a pair (a, b'), a in the first half of its run,
+ * dmask[a] = sum (X[b'] - X[a]) * (G[a] - G[b']); all other entries 0.  g NCTHW (g_cpad 0) or
+ * channels-last; workspace: ivf_freeze_bwd_workspace_bytes(B, T). */
+int ivf_reverse_bwd(const float* x, const int* partner, const float* g, float* dmask, int B, int C, int T,
+                    int HW, int g_cpad, void* workspace, ivf_stream_t stream);
+
 /* mask.calc_tv_norm(mask, p, q), mask.py:88-100: val[b] and (optional) grad[b,:]. */
 int ivf_tv_norm(const float* mask, int B, int T, float p, float q, float* val, float* grad,
                 ivf_stream_t stream);
@@ -296,10 +309,12 @@ int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** ptr, int* T
  * device: N iterations of sigmoid/L1/TV -> freeze -> forward -> score -> backward
  * -> freeze backward -> Adam.  raw_mask, exp_avg, exp_avg_sq [b,T] in/out;
  * target [b]; traj [N,b,4] = (loss,l1,tv,score) or NULL; first_step = Adam step
- * number of the first iteration (1 for a fresh search). */
+ * number of the first iteration (1 for a fresh search); mode = the perturbation the loop
+ * optimises through (temporalMaskType, smth:121,202): 0 freeze, 1 reverse. */
 int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* target, float* raw_mask,
                    float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
-                   float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream);
+                   float beta2, float eps, int N, int first_step, int mode, float* traj,
+                   ivf_stream_t stream);
 
 /* Scores of perturbed clips (init_mask, mask.py:121-154, and the reverse score,
  * smth:234-235): mode 0 = freeze with mask [b,T] as given (no sigmoid), mode 1 =
@@ -359,7 +374,8 @@ int ivf_clstm_backward(ivf_clstm_t* net, int b, const int* target, const float* 
 /* The hot loop (KTH:250-270) with the ConvLSTM backbone; arguments as ivf_i3d_search. */
 int ivf_clstm_search(ivf_clstm_t* net, const float* x, int b, const int* target, float* raw_mask,
                      float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
-                     float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream);
+                     float beta2, float eps, int N, int first_step, int mode, float* traj,
+                     ivf_stream_t stream);
 int ivf_clstm_perturbed_forward(ivf_clstm_t* net, const float* x, int b, const float* mask, int mode,
                                 float* probs, ivf_stream_t stream);
 
@@ -387,6 +403,8 @@ double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net);
 int ivf_profile_enable(int every, int max_launches);
 int ivf_profile_disable(void);
 int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);
+/* Kernel template instance behind a class id ("" until that class has been launched). */
+const char* ivf_profile_class_name(int cls);
 
 #ifdef __cplusplus
 }

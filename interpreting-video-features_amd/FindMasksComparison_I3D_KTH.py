@@ -52,8 +52,10 @@ def main(argv=None):
         loader = ivf_find_masks.SyntheticLoader(args.synthetic, config['batch_size'],
                                                 (3, config['clip_size'], 120, 160), config['num_classes'])
     else:
-        raise SystemExit("dataset ingest (data_loader_kth.KTHImLoader) is the next row of SURVEY.md 8f; "
-                         "run with --synthetic N or call find_masks() with your own loader")
+        import ivf_ingest
+        loader = ivf_ingest.JpegFolderLoader(config['data_folder'] + "/test", clip_size=config['clip_size'],
+                                             batch_size=config['batch_size'], layout="kth",
+                                             drop_last=True, device=device)     # val_loader, KTH:73-78
     config.setdefault("gradCamType", args.gradCamType)
     find_masks(loader, model, config, lam1, lam2, N, 1, "central", config.get("maskPerturbType", "freeze"),
                classOI=None, doGradCam=config['conv_model'].endswith("CLSTM_4") is False, runTempMask=True)

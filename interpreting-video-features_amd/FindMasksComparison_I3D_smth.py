@@ -50,8 +50,10 @@ def main(argv=None):
         loader = ivf_find_masks.SyntheticLoader(args.synthetic, config['batch_size'],
                                                 (3, config['clip_size'], 224, 224), config['num_classes'])
     else:
-        raise SystemExit("dataset ingest (data_loader_jpg.ImLoader) is the next row of SURVEY.md 8f; "
-                         "run with --synthetic N or call find_masks() with your own loader")
+        import ivf_ingest
+        loader = ivf_ingest.JpegFolderLoader(config['data_folder'] + "/validation/", clip_size=config['clip_size'],
+                                             batch_size=config['batch_size'], layout="smth",
+                                             drop_last=True, device=device)     # val_loader, smth:71-77
     config.setdefault("gradCamType", args.gradCamType)
     find_masks(loader, model, config, lam1, lam2, N, "central", config.get("maskPerturbType", "freeze"),
                classOI=args.subsetFile, doGradCam=True, runTempMask=True)

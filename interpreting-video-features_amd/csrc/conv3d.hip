@@ -464,12 +464,15 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   const int cls = BM == 64 ? (BN == 64 ? 10 : 11)
                   : BN > 128 ? (BN == 256 ? 7 : (BN == 192 ? 8 : 9))
                              : IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0);
-  const bool timed = prof_begin(s, cls);
   if constexpr (BN > 128 || BM == 64) {
     if (math == 0) {
       set_error("conv3d: wide implicit-GEMM tiles exist for split-bf16 only");
       return IVF_ERR_UNSUPPORTED;
     }
+  }
+  prof_name(cls, "%s<%d,%d,%d,%d>", math ? "conv3d_igemm_bf16x3_kernel" : "conv3d_igemm_kernel", BM, BN, WM, WN);
+  const bool timed = prof_begin(s, cls);
+  if constexpr (BN > 128 || BM == 64) {
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
   } else if (math == 0)
     hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);

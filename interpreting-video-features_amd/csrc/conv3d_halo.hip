@@ -480,6 +480,8 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   a.ntiles = cdiv(a.Cout, BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
+  prof_name(IVF_CONV_HALO_BASE + variant_id, "conv3d_halo_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", TT, BN, WROWS, WCOLS, KS, BKH,
+            TH, TW);
   const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
   hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);

@@ -296,6 +296,7 @@ int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s) {
   const int tilesT = cdiv(a.To, P4_TT), tilesH = cdiv(a.Ho, P4_TH), tilesW = cdiv(a.Wo, P4_TW);
   a.ntiles = cdiv(a.Cout, P4_BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
+  prof_name(variant_id, "conv3d_pix4_kernel");
   const bool timed = prof_begin(s, variant_id);
   static int cus = 0;
   if (!cus) {

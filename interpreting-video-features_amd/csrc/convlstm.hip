@@ -472,49 +472,6 @@ __global__ void clstm_fill_kernel(float* p, long n, float v) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// per-clip reverse pairing + NCTHW reverse perturbation (mask.py:24-56) for b masks
-__global__ void clstm_pairs_kernel(const float* __restrict__ mask, int b, int T, float thresh,
-                                   int* __restrict__ partner, float* __restrict__ weight) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  const float* m = mask + (long)i * T;
-  int* pr = partner + (long)i * T;
-  float* wt = weight + (long)i * T;
-  int start = -1;
-  for (int j = 0; j <= T; ++j) {
-    bool on = (j < T) && (m[j] > thresh);
-    if (j < T) { pr[j] = j; wt[j] = 0.f; }
-    if (on && start < 0) start = j;
-    if (!on && start >= 0) {
-      int len = j - start;
-      for (int u = 0; u < len / 2; ++u) {
-        int a = start + u, bb = start + len - 1 - u;
-        pr[a] = bb; pr[bb] = a; wt[a] = m[a]; wt[bb] = m[a];
-      }
-      start = -1;
-    }
-  }
-}
-
-__global__ void clstm_reverse_kernel(const float* __restrict__ x, const int* __restrict__ partner,
-                                     const float* __restrict__ weight, float* __restrict__ p, int B, int C, int T,
-                                     int HW) {
-  long total = (long)B * C * T * HW;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int px = i % HW;
-    int t = (i / HW) % T;
-    long bc = i / ((long)HW * T);
-    int b = bc / C;
-    int pt = partner[b * T + t];
-    float v = x[i];
-    if (pt != t) {
-      float w = weight[b * T + t];
-      v = (1.f - w) * v + w * x[(bc * T + pt) * HW + px];
-    }
-    p[i] = v;
-  }
-}
-
 static inline int grid_for(long total, int block = 256, int cap = 4096) {
   long g = (total + block - 1) / block;
   return (int)(g > cap ? cap : (g ? g : 1));
@@ -841,10 +798,12 @@ extern "C" int ivf_clstm_backward(ivf_clstm_t* n, int b, const int* target, cons
 
 extern "C" int ivf_clstm_search(ivf_clstm_t* n, const float* x, int b, const int* target, float* raw_mask,
                                 float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr, float beta1,
-                                float beta2, float eps, int N, int first_step, float* traj, ivf_stream_t stream) {
+                                float beta2, float eps, int N, int first_step, int mode, float* traj,
+                                ivf_stream_t stream) {
   IVF_PROPAGATE(clstm_ready(n, b));
   IVF_CHECK_ARG(x && target && raw_mask && exp_avg && exp_avg_sq, "clstm_search: null pointer");
   IVF_CHECK_ARG(N >= 0 && first_step >= 1, "clstm_search: bad iteration counts");
+  IVF_CHECK_ARG(mode == 0 || mode == 1, "clstm_search: mode must be 0 (freeze) or 1 (reverse)");
   const ivf_clstm_config& c = n->cfg;
   hipStream_t s = (hipStream_t)stream;
   const int T = c.T, HW = c.H * c.W;
@@ -855,12 +814,22 @@ extern "C" int ivf_clstm_search(ivf_clstm_t* n, const float* x, int b, const int
   float* score = n->at<float>(n->off_score);
   float* P = n->at<float>(n->off_p);
   float* dP = n->at<float>(n->off_dp);
+  int* partner = n->at<int>(n->off_pair);
+  float* weight = (float*)(partner + (size_t)c.B * c.T);
   for (int it = 0; it < N; ++it) {
     IVF_PROPAGATE(ivf_mask_reg(raw_mask, b, T, lam1, lam2, sig, terms, dreg, s));
-    IVF_PROPAGATE(ivf_freeze_fwd(x, sig, P, b, c.C, T, HW, 1, 0, s));
+    if (mode == 0) {
+      IVF_PROPAGATE(ivf_freeze_fwd(x, sig, P, b, c.C, T, HW, 1, 0, s));
+    } else {
+      IVF_PROPAGATE(ivf_submask_pairs_batched(sig, b, T, 0.1f, partner, weight, s));
+      IVF_PROPAGATE(ivf_reverse_fwd_batched(x, partner, weight, P, b, c.C, T, HW, 0, s));
+    }
     IVF_PROPAGATE(clstm_run_forward(n, P, b, nullptr, nullptr, s));
     IVF_PROPAGATE(clstm_run_backward(n, b, target, nullptr, score, dP, s));
-    IVF_PROPAGATE(ivf_freeze_bwd(x, sig, dP, dsig, nullptr, b, c.C, T, HW, 1, 0, n->at<void>(n->off_fbwd), s));
+    if (mode == 0)
+      IVF_PROPAGATE(ivf_freeze_bwd(x, sig, dP, dsig, nullptr, b, c.C, T, HW, 1, 0, n->at<void>(n->off_fbwd), s));
+    else
+      IVF_PROPAGATE(ivf_reverse_bwd(x, partner, dP, dsig, b, c.C, T, HW, 0, n->at<void>(n->off_fbwd), s));
     IVF_PROPAGATE(ivf_search_step(raw_mask, sig, dsig, dreg, terms, score, exp_avg, exp_avg_sq,
                                   traj ? traj + (size_t)it * b * 4 : nullptr, b, T, first_step + it, lr, beta1,
                                   beta2, eps, s));
@@ -880,11 +849,8 @@ extern "C" int ivf_clstm_perturbed_forward(ivf_clstm_t* n, const float* x, int b
   } else {
     int* partner = n->at<int>(n->off_pair);
     float* weight = (float*)(partner + (size_t)c.B * c.T);
-    hipLaunchKernelGGL(clstm_pairs_kernel, dim3(cdiv(b, 64)), dim3(64), 0, s, mask, b, c.T, 0.1f, partner, weight);
-    IVF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(clstm_reverse_kernel, dim3(grid_for((long)b * c.C * c.T * c.H * c.W)), dim3(256), 0, s, x,
-                       partner, weight, P, b, c.C, c.T, c.H * c.W);
-    IVF_CHECK_LAUNCH();
+    IVF_PROPAGATE(ivf_submask_pairs_batched(mask, b, c.T, 0.1f, partner, weight, s));
+    IVF_PROPAGATE(ivf_reverse_fwd_batched(x, partner, weight, P, b, c.C, c.T, c.H * c.W, 0, s));
   }
   return clstm_run_forward(n, P, b, nullptr, probs, s);
 }

@@ -492,51 +492,6 @@ __global__ void cl4_to_ncthw_kernel(const float* __restrict__ y, float* __restri
   }
 }
 
-// per-clip reverse pairing for b masks (one thread per clip; see mask_ops.hip)
-__global__ void pairs_batched_kernel(const float* __restrict__ mask, int b, int T, float thresh,
-                                     int* __restrict__ partner, float* __restrict__ weight) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  const float* m = mask + (size_t)i * T;
-  int* pr = partner + (size_t)i * T;
-  float* wt = weight + (size_t)i * T;
-  int start = -1;
-  for (int j = 0; j <= T; ++j) {
-    bool on = (j < T) && (m[j] > thresh);
-    if (j < T) { pr[j] = j; wt[j] = 0.f; }
-    if (on && start < 0) start = j;
-    if (!on && start >= 0) {
-      int len = j - start;
-      for (int u = 0; u < len / 2; ++u) {
-        int a = start + u, bb = start + len - 1 - u;
-        pr[a] = bb; pr[bb] = a; wt[a] = m[a]; wt[bb] = m[a];
-      }
-      start = -1;
-    }
-  }
-}
-
-__global__ void reverse_cl4_batched_kernel(const float* __restrict__ x, const int* __restrict__ partner,
-                                           const float* __restrict__ weight, float* __restrict__ p, int B,
-                                           int C, int T, int HW) {
-  size_t total = (size_t)B * T * HW;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    int px = i % HW;
-    int t = (i / HW) % T;
-    int b = i / ((size_t)HW * T);
-    int pt = partner[b * T + t];
-    float w = weight[b * T + t];
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < C; ++c) {
-      float xv = x[((size_t)(b * C + c) * T + t) * HW + px];
-      if (pt != t) xv = (1.f - w) * xv + w * x[((size_t)(b * C + c) * T + pt) * HW + px];
-      v[c] = xv;
-    }
-    *reinterpret_cast<float4*>(p + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-}
-
 static inline int grid_for(size_t total, int block = 256, int cap = 4096) {
   size_t g = (total + block - 1) / block;
   return (int)(g > (size_t)cap ? cap : (g ? g : 1));
@@ -696,11 +651,12 @@ extern "C" int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** 
 
 extern "C" int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* target, float* raw_mask,
                               float* exp_avg, float* exp_avg_sq, float lam1, float lam2, float lr,
-                              float beta1, float beta2, float eps, int N, int first_step, float* traj,
-                              ivf_stream_t stream) {
+                              float beta1, float beta2, float eps, int N, int first_step, int mode,
+                              float* traj, ivf_stream_t stream) {
   IVF_PROPAGATE(check_ready(net, b));
   IVF_CHECK_ARG(x && target && raw_mask && exp_avg && exp_avg_sq, "i3d_search: null pointer");
   IVF_CHECK_ARG(N >= 0 && first_step >= 1, "i3d_search: bad iteration counts");
+  IVF_CHECK_ARG(mode == 0 || mode == 1, "i3d_search: mode must be 0 (freeze) or 1 (reverse)");
   const ivf_i3d_config& c = net->cfg;
   hipStream_t s = (hipStream_t)stream;
   const int T = c.T, HW = c.H * c.W;
@@ -709,14 +665,25 @@ extern "C" int ivf_i3d_search(ivf_i3d_t* net, const float* x, int b, const int* 
   float* dreg = net->at<float>(net->off_dreg);
   float* dsig = net->at<float>(net->off_dsig);
   float* score = net->at<float>(net->off_score);
+  int* partner = net->at<int>(net->off_pair);
+  float* weight = (float*)(partner + (size_t)c.B * c.T);
   for (int it = 0; it < N; ++it) {
     prof_set_iteration(it);
     IVF_PROPAGATE(ivf_mask_reg(raw_mask, b, T, lam1, lam2, sig, terms, dreg, s));              // smth:198-200
-    IVF_PROPAGATE(ivf_freeze_fwd(x, sig, net->act(0), b, c.C, T, HW, 1, 4, s));                // smth:202
+    if (mode == 0) {
+      IVF_PROPAGATE(ivf_freeze_fwd(x, sig, net->act(0), b, c.C, T, HW, 1, 4, s));              // smth:202
+    } else {
+      IVF_PROPAGATE(ivf_submask_pairs_batched(sig, b, T, 0.1f, partner, weight, s));
+      IVF_PROPAGATE(ivf_reverse_fwd_batched(x, partner, weight, net->act(0), b, c.C, T, HW, 4, s));
+    }
     IVF_PROPAGATE(run_forward(net, b, nullptr, nullptr, s));                                    // smth:202-205
     IVF_PROPAGATE(run_backward(net, b, target, nullptr, score, s));                             // smth:213
-    IVF_PROPAGATE(ivf_freeze_bwd(x, sig, net->grad(0), dsig, nullptr, b, c.C, T, HW, 1, 4,
-                                 net->at<void>(net->off_fbwd), s));
+    if (mode == 0)
+      IVF_PROPAGATE(ivf_freeze_bwd(x, sig, net->grad(0), dsig, nullptr, b, c.C, T, HW, 1, 4,
+                                   net->at<void>(net->off_fbwd), s));
+    else
+      IVF_PROPAGATE(ivf_reverse_bwd(x, partner, net->grad(0), dsig, b, c.C, T, HW, 4,
+                                    net->at<void>(net->off_fbwd), s));
     IVF_PROPAGATE(ivf_search_step(raw_mask, sig, dsig, dreg, terms, score, exp_avg, exp_avg_sq,
                                   traj ? traj + (size_t)it * b * 4 : nullptr, b, T, first_step + it, lr,
                                   beta1, beta2, eps, s));                                       // smth:207-214
@@ -736,12 +703,8 @@ extern "C" int ivf_i3d_perturbed_forward(ivf_i3d_t* net, const float* x, int b, 
   } else {
     int* partner = net->at<int>(net->off_pair);
     float* weight = (float*)(partner + (size_t)c.B * c.T);
-    hipLaunchKernelGGL(pairs_batched_kernel, dim3(cdiv(b, 64)), dim3(64), 0, s, mask, b, c.T, 0.1f, partner,
-                       weight);
-    IVF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reverse_cl4_batched_kernel, dim3(grid_for((size_t)b * c.T * c.H * c.W)), dim3(256), 0,
-                       s, x, partner, weight, net->act(0), b, c.C, c.T, c.H * c.W);
-    IVF_CHECK_LAUNCH();
+    IVF_PROPAGATE(ivf_submask_pairs_batched(mask, b, c.T, 0.1f, partner, weight, s));
+    IVF_PROPAGATE(ivf_reverse_fwd_batched(x, partner, weight, net->act(0), b, c.C, c.T, c.H * c.W, 4, s));
   }
   return run_forward(net, b, nullptr, probs, s);
 }

@@ -16,6 +16,7 @@ void prof_set_iteration(int it);
 void prof_set_flops(double algorithmic_flops);
 bool prof_begin(hipStream_t s, int variant);
 void prof_end(hipStream_t s);
+void prof_name(int variant, const char* fmt, ...);   // kernel name of a profiler class (first call wins)
 
 #define IVF_CHECK_ARG(cond, ...)                 \
   do {                                           \

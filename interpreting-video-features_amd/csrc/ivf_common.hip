@@ -32,6 +32,14 @@ struct Prof {
   double next_flops = 0.0;
 };
 static Prof g_prof;
+static char g_prof_names[IVF_PROFILE_CLASSES][96];
+void prof_name(int variant, const char* fmt, ...) {
+  if (variant < 0 || variant >= IVF_PROFILE_CLASSES || g_prof_names[variant][0]) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_prof_names[variant], sizeof(g_prof_names[variant]), fmt, ap);
+  va_end(ap);
+}
 void prof_set_iteration(int it) { g_prof.active = g_prof.enabled && it >= 0 && (it % g_prof.every == 0); }
 void prof_set_flops(double f) { g_prof.next_flops = f; }
 bool prof_begin(hipStream_t s, int variant) {
@@ -71,6 +79,11 @@ extern "C" int ivf_profile_disable(void) {
   ivf::g_prof.enabled = false;
   ivf::g_prof.active = false;
   return IVF_OK;
+}
+
+// Kernel (template instance) behind a profiler class id; "" until that class has launched.
+extern "C" const char* ivf_profile_class_name(int cls) {
+  return (cls >= 0 && cls < IVF_PROFILE_CLASSES) ? ivf::g_prof_names[cls] : "";
 }
 
 // Sums per kernel variant id v in [0,IVF_PROFILE_CLASSES): kernel_ms[v], launches[v], flops[v];

@@ -259,6 +259,90 @@ __global__ void reverse_fwd_kernel(const float* __restrict__ x, const int* __res
   }
 }
 
+// ---------------------------------------------------------------- reverse, per-clip masks
+// The batched forms used by the search loops: clip b has its own mask row, hence its own
+// pairing (partner/weight rows [B,T]).
+__global__ void submask_pairs_batched_kernel(const float* __restrict__ mask, int B, int T, float thresh,
+                                             int* __restrict__ partner, float* __restrict__ weight) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float* m = mask + (size_t)i * T;
+  int* pr = partner + (size_t)i * T;
+  float* wt = weight + (size_t)i * T;
+  int start = -1;
+  for (int j = 0; j <= T; ++j) {
+    bool on = (j < T) && (m[j] > thresh);
+    if (j < T) { pr[j] = j; wt[j] = 0.f; }
+    if (on && start < 0) start = j;
+    if (!on && start >= 0) {
+      int len = j - start;
+      for (int u = 0; u < len / 2; ++u) {
+        int a = start + u, bb = start + len - 1 - u;
+        pr[a] = bb; pr[bb] = a; wt[a] = m[a]; wt[bb] = m[a];   // mask.py:50-56: m[a] for both
+      }
+      start = -1;
+    }
+  }
+}
+
+// one thread per (b, t, pixel): all C channels, NCTHW or 16-byte channels-last output
+__global__ void reverse_fwd_batched_kernel(const float* __restrict__ x, const int* __restrict__ partner,
+                                           const float* __restrict__ weight, float* __restrict__ p, int B,
+                                           int C, int T, int HW, int out_cpad) {
+  size_t total = (size_t)B * T * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int px = i % HW;
+    int t = (i / HW) % T;
+    int b = i / ((size_t)HW * T);
+    int pt = partner[b * T + t];
+    float w = weight[b * T + t];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      float xv = x[((size_t)(b * C + c) * T + t) * HW + px];
+      if (pt != t) xv = (1.f - w) * xv + w * x[((size_t)(b * C + c) * T + pt) * HW + px];
+      if (out_cpad == 0) p[((size_t)(b * C + c) * T + t) * HW + px] = xv;
+      v[c & 3] = xv;
+    }
+    if (out_cpad == 4) *reinterpret_cast<float4*>(p + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// d(loss)/d(mask) of the reverse perturbation (autograd of mask.py:49-56).  For a pair (a, b'),
+// a in the first half of its run:  P[a] = (1-m[a]) X[a] + m[a] X[b'],  P[b'] = (1-m[a]) X[b'] + m[a] X[a]
+//   => dL/dm[a] = sum_{c,px} (X[b'] - X[a]) * (G[a] - G[b']);  every other entry is 0
+// (the run detection `mask > 0.1` is not differentiable).  Block partials + fixed-order
+// reduction, as in the freeze backward.
+__global__ __launch_bounds__(256) void reverse_bwd_kernel(
+    const float* __restrict__ x, const int* __restrict__ partner, const float* __restrict__ g,
+    float* __restrict__ partial, int B, int C, int T, int HW, int g_cpad, int blocks_per_clip) {
+  const int b = blockIdx.x / blocks_per_clip;
+  const int blk = blockIdx.x % blocks_per_clip;
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = 0; t < T; ++t) {
+    const int pt = partner[b * T + t];
+    float acc = 0.f;
+    if (pt > t) {   // block-uniform
+      for (int i = blk * blockDim.x + threadIdx.x; i < C * HW; i += blocks_per_clip * blockDim.x) {
+        int px = i % HW, c = i / HW;
+        float xa = x[((size_t)(b * C + c) * T + t) * HW + px];
+        float xb = x[((size_t)(b * C + c) * T + pt) * HW + px];
+        float ga = g_cpad ? g[((size_t)(b * T + t) * HW + px) * g_cpad + c] : g[((size_t)(b * C + c) * T + t) * HW + px];
+        float gb = g_cpad ? g[((size_t)(b * T + pt) * HW + px) * g_cpad + c] : g[((size_t)(b * C + c) * T + pt) * HW + px];
+        acc += (xb - xa) * (ga - gb);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[((size_t)b * blocks_per_clip + blk) * T + t] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
 __global__ void zero_kernel(float* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
@@ -369,8 +453,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // Search-loop tail (FindMasksComparison_I3D_smth.py:207-214): total gradient w.r.t.
 // the raw mask = (dscore/dsig + dreg/dsig) * sig*(1-sig); record (loss, l1, tv, score)
-// and take the Adam step.  dsig[b,0] is forced to the regulariser part only because
-// m[0] never enters the freeze recurrence (mask.py:16-18).
+// and take the Adam step.  (For 'freeze' m[0] never enters the recurrence, mask.py:16-18:
+// ivf_freeze_bwd writes an exact 0 there; for 'reverse' frame 0 may belong to a run.)
 __global__ void search_step_kernel(float* __restrict__ raw, const float* __restrict__ sig,
                                    const float* __restrict__ dscore_dsig,
                                    const float* __restrict__ dreg, const float* __restrict__ terms,
@@ -382,7 +466,7 @@ __global__ void search_step_kernel(float* __restrict__ raw, const float* __restr
   if (i >= B * T) return;
   int b = i / T, u = i % T;
   float s = sig[i];
-  float gs = dreg[i] + (u > 0 ? dscore_dsig[i] : 0.f);
+  float gs = dreg[i] + dscore_dsig[i];
   float gi = gs * (s * (1.f - s));
   float mi = am[i] * b1 + (1.f - b1) * gi;
   float vi = av[i] * b2 + (1.f - b2) * gi * gi;
@@ -494,6 +578,42 @@ extern "C" int ivf_reverse_fwd(const float* x, const int* partner, const float* 
   }
   hipLaunchKernelGGL(reverse_fwd_kernel, dim3(grid_for((size_t)B * C * T * HW)), dim3(256), 0, s, x,
                      partner, weight, p, B, C, T, HW, out_cpad);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_submask_pairs_batched(const float* mask, int B, int T, float thresh, int* partner,
+                                         float* weight, ivf_stream_t stream) {
+  IVF_CHECK_ARG(mask && partner && weight && B > 0 && T > 0, "submask_pairs_batched: bad args");
+  hipLaunchKernelGGL(submask_pairs_batched_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, mask, B,
+                     T, thresh, partner, weight);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_reverse_fwd_batched(const float* x, const int* partner, const float* weight, float* p,
+                                       int B, int C, int T, int HW, int out_cpad, ivf_stream_t stream) {
+  IVF_CHECK_ARG(x && partner && weight && p, "reverse_fwd_batched: null pointer");
+  IVF_CHECK_ARG(B > 0 && C > 0 && T > 0 && HW > 0, "reverse_fwd_batched: bad dims");
+  IVF_CHECK_ARG(out_cpad == 0 || (out_cpad == 4 && C <= 4), "reverse_fwd_batched: out_cpad must be 0 or 4 (C <= 4)");
+  hipLaunchKernelGGL(reverse_fwd_batched_kernel, dim3(grid_for((size_t)B * T * HW, 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, x, partner, weight, p, B, C, T, HW, out_cpad);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_reverse_bwd(const float* x, const int* partner, const float* g, float* dmask, int B, int C,
+                               int T, int HW, int g_cpad, void* workspace, ivf_stream_t stream) {
+  IVF_CHECK_ARG(x && partner && g && dmask && workspace, "reverse_bwd: null pointer");
+  IVF_CHECK_ARG(B > 0 && C > 0 && T > 0 && T <= MAX_T && HW > 0, "reverse_bwd: bad dims (T <= %d)", MAX_T);
+  IVF_CHECK_ARG(g_cpad == 0 || g_cpad >= C, "reverse_bwd: g_cpad < C");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;   // ivf_freeze_bwd_workspace_bytes(B, T)
+  const int bpc = FREEZE_BWD_BLOCKS_PER_CLIP;
+  hipLaunchKernelGGL(reverse_bwd_kernel, dim3(B * bpc), dim3(256), 0, s, x, partner, g, partial, B, C, T, HW,
+                     g_cpad, bpc);
+  IVF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(freeze_bwd_reduce_kernel, dim3(cdiv(B * T, 64)), dim3(64), 0, s, partial, dmask, B, T, bpc);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }

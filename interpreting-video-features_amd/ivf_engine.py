@@ -21,6 +21,16 @@ DEFAULT_MATH = os.environ.get("IVF_MATH", "bf16x3")
 AUTOTUNE = os.environ.get("IVF_AUTOTUNE", "1") != "0"
 
 
+def _mode_id(mode):
+    """perturbation type -> the C-ABI's mode id; anything else fails as the reference's
+    perturb_sequence does (mask.py:57 returns an unset local)."""
+    if mode == "freeze":
+        return 0
+    if mode == "reverse":
+        return 1
+    raise UnboundLocalError("local variable 'perturbed_input' referenced before assignment")
+
+
 def _arena(nbytes, device):
     # torch's caching allocator returns >=512-byte aligned blocks
     t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -179,9 +189,10 @@ class I3DEngine:
         return flat.view(b, T.value, H.value, W.value, ld.value)[..., :C.value].permute(0, 4, 1, 2, 3).contiguous()
 
     def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
-               state=None, want_traj=True):
+               state=None, want_traj=True, mode="freeze"):
         """N iterations of the hot loop (smth:193-214) on b clips.  raw_mask [b,T] is
-        updated in place; state = (exp_avg, exp_avg_sq, steps_done) continues a search."""
+        updated in place; state = (exp_avg, exp_avg_sq, steps_done) continues a search;
+        mode = the perturbation the loop optimises through (temporalMaskType, smth:121,202)."""
         x = self._clip(x)
         b = x.shape[0]
         T = self.clip_shape[1]
@@ -196,7 +207,7 @@ class I3DEngine:
         with torch.cuda.device(self.device):
             L.check(L.lib().ivf_i3d_search(self._h, L.ptr(x), b, L.ptr(tgt), L.ptr(raw_mask), L.ptr(m), L.ptr(v),
                                            lam1, lam2, lr, betas[0], betas[1], eps, int(N), done + 1,
-                                           L.ptr(traj), L.stream()))
+                                           _mode_id(mode), L.ptr(traj), L.stream()))
         return traj, (m, v, done + int(N))
 
     def perturbed_forward(self, x, mask, mode="freeze"):
@@ -208,7 +219,7 @@ class I3DEngine:
         probs = torch.empty(b, self.K, device=self.device)
         with torch.cuda.device(self.device):
             L.check(L.lib().ivf_i3d_perturbed_forward(self._h, L.ptr(x), b, L.ptr(mask),
-                                                      0 if mode == "freeze" else 1, L.ptr(probs), L.stream()))
+                                                      _mode_id(mode), L.ptr(probs), L.stream()))
         return probs
 
     def argmax(self, probs):
@@ -321,7 +332,7 @@ class CLSTMEngine:
         return score, dx
 
     def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
-               state=None, want_traj=True):
+               state=None, want_traj=True, mode="freeze"):
         x = self._clip(x)
         b = x.shape[0]
         T = self.clip_shape[1]
@@ -336,7 +347,7 @@ class CLSTMEngine:
         with torch.cuda.device(self.device):
             L.check(L.lib().ivf_clstm_search(self._h, L.ptr(x), b, L.ptr(tgt), L.ptr(raw_mask), L.ptr(m), L.ptr(v),
                                              lam1, lam2, lr, betas[0], betas[1], eps, int(N), done + 1,
-                                             L.ptr(traj), L.stream()))
+                                             _mode_id(mode), L.ptr(traj), L.stream()))
         return traj, (m, v, done + int(N))
 
     def perturbed_forward(self, x, mask, mode="freeze"):
@@ -348,7 +359,7 @@ class CLSTMEngine:
         probs = torch.empty(b, self.K, device=self.device)
         with torch.cuda.device(self.device):
             L.check(L.lib().ivf_clstm_perturbed_forward(self._h, L.ptr(x), b, L.ptr(mask),
-                                                        0 if mode == "freeze" else 1, L.ptr(probs), L.stream()))
+                                                        _mode_id(mode), L.ptr(probs), L.stream()))
         return probs
 
     def gradcam(self, *a, **kw):

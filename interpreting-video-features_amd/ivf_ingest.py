@@ -52,3 +52,55 @@ def ingest_u8(frames, layout=NCTHW, cpad=4, out=None):
         raise ValueError(f"out must be a contiguous float32 tensor of shape {shape}")
     L.check(L.lib().ivf_clip_ingest_u8(L.ptr(t), L.ptr(out), B, T, H, W, C, layout, cpad, L.stream()))
     return out[0] if unbatched else out
+
+
+class JpegFolderLoader:
+    """The reference's `DataLoader(ImLoader | KTHImLoader, batch_size, shuffle=False, drop_last=True)`
+    as the drivers build it (smth:66-77, KTH:66-84), with the cast + permute on the device:
+    yields (sequence float32 [B,3,T,H,W] on the GPU, label LongTensor [B], ids list).
+
+    layout "smth": root/<class id>/<clip id>/frameNN.jpg  (PicDatabase, data_parser.py:121-131;
+                   clips in os.walk order, label = class directory name, id = clip directory name)
+    layout "kth":  root/<index>/frameNN.jpg + class.txt + label.txt, index = 0 .. len(listdir)-1
+                   (data_loader_kth.py:20-47; id = the text of label.txt)
+    """
+
+    def __init__(self, root, clip_size=16, batch_size=16, layout="smth", drop_last=True, device=None):
+        if layout not in ("smth", "kth"):
+            raise ValueError("layout must be 'smth' or 'kth'")
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"clip folder '{root}' does not exist")
+        self.root, self.clip_size, self.batch_size = root, int(clip_size), int(batch_size)
+        self.layout, self.drop_last, self.device = layout, drop_last, device
+        self.items = []                      # (folder, label or None, id or None)
+        if layout == "smth":
+            for cls in next(os.walk(root))[1]:
+                for clip in next(os.walk(os.path.join(root, cls)))[1]:
+                    self.items.append((os.path.join(root, cls, clip), int(cls), clip))
+        else:
+            for index in range(len(os.listdir(root))):
+                self.items.append((os.path.join(root, str(index)), None, None))
+
+    def __len__(self):
+        n = len(self.items)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def _item(self, i):
+        folder, label, cid = self.items[i]
+        frames = decode_clip_u8(folder, self.clip_size)
+        if self.layout == "kth":
+            with open(os.path.join(folder, "class.txt")) as f:
+                label = int(f.readline())
+            with open(os.path.join(folder, "label.txt")) as f:
+                cid = f.readline()
+        return frames, label, cid
+
+    def __iter__(self):
+        n = len(self.items)
+        stop = n - n % self.batch_size if self.drop_last else n
+        for s in range(0, stop, self.batch_size):
+            got = [self._item(i) for i in range(s, min(s + self.batch_size, stop))]
+            frames = np.stack([g[0] for g in got])
+            with torch.cuda.device(self.device if self.device is not None else torch.cuda.current_device()):
+                seq = ingest_u8(frames, NCTHW)
+            yield seq, torch.tensor([g[1] for g in got], dtype=torch.long), [g[2] for g in got]

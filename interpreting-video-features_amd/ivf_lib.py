@@ -64,6 +64,9 @@ _SIGS = {
     "ivf_freeze_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ivf_submask_pairs": (c_int, [_P, _I, _F, _P, _P, _P, _P]),
     "ivf_reverse_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ivf_submask_pairs_batched": (c_int, [_P, _I, _I, _F, _P, _P, _P]),
+    "ivf_reverse_fwd_batched": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ivf_reverse_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ivf_tv_norm": (c_int, [_P, _I, _I, _F, _F, _P, _P, _P]),
     "ivf_mask_reg": (c_int, [_P, _I, _I, _F, _F, _P, _P, _P, _P]),
     "ivf_adam_step": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P]),
@@ -100,7 +103,7 @@ _SIGS = {
     "ivf_i3d_input_grad_buffer": (c_void_p, [_P]),
     "ivf_i3d_backward": (c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "ivf_i3d_endpoint": (c_int, [_P, c_char_p, POINTER(c_void_p)] + [POINTER(c_int)] * 5),
-    "ivf_i3d_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "ivf_i3d_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     "ivf_i3d_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
     "ivf_i3d_gradcam": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "ivf_i3d_conv_flops_per_clip": (ctypes.c_double, [_P]),
@@ -113,6 +116,7 @@ _SIGS = {
     "ivf_profile_disable": (c_int, []),
     "ivf_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),
                                     POINTER(ctypes.c_double)]),
+    "ivf_profile_class_name": (c_char_p, [_I]),
 }
 
 # csrc/convlstm.hip
@@ -126,7 +130,7 @@ _SIGS_OPT = {
     "ivf_clstm_load_head": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "ivf_clstm_forward": (c_int, [_P, _P, _I, _P, _P, _P]),
     "ivf_clstm_backward": (c_int, [_P, _I, _P, _P, _P, _P, _P]),
-    "ivf_clstm_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "ivf_clstm_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     "ivf_clstm_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
 }
 

@@ -37,7 +37,8 @@ def init_masks_central(engine, x, target, orig_score, threshold=0.9, mask_type="
     dev = x.device
     idx = torch.arange(b, device=dev)
     tl = target.long()
-    full = engine.perturbed_forward(x, torch.ones(b, T, device=dev), mask_type)[idx, tl]   # :123-128
+    # the fully perturbed clip is ALWAYS the fully frozen one (mask.py:123-128), whatever mask_type
+    full = engine.perturbed_forward(x, torch.ones(b, T, device=dev), "freeze")[idx, tl]
     cands = central_masks(T, dev)
     cen = torch.stack([engine.perturbed_forward(x, cands[i][None].expand(b, T).contiguous(), mask_type)[idx, tl]
                        for i in range(cands.shape[0])], dim=1)                                # :139-141
@@ -106,7 +107,7 @@ class MaskSearch:
                                            self.mask_type)                   # smth:188-190
             out["init_mask"] = raw.clone()
             traj, _ = eng.search(x, target, raw, self.lam1, self.lam2, self.n_iter, lr=self.lr,
-                                 want_traj=True)                             # smth:191-214
+                                 want_traj=True, mode=self.mask_type)        # smth:191-214
             mask = torch.sigmoid(raw)                                        # smth:216
             out["time_mask"] = mask
             out["freeze_score"] = traj[-1, :, 3] if self.n_iter > 0 else torch.full((b,), float("nan"), device=dev)
@@ -123,21 +124,29 @@ class MaskSearch:
         return out
 
 
-RECORD_FIELDS = ("clip_id", "pred_class", "target", "original_score_guess", "original_score_true",
-                 "freeze_score", "reverse_score")
+RECORD_INT_FIELDS = ("clip_id", "pred_class", "target")
+RECORD_FLOAT_FIELDS = ("original_score_guess", "original_score_true", "freeze_score", "reverse_score")
+RECORD_FIELDS = RECORD_INT_FIELDS + RECORD_FLOAT_FIELDS
 
 
 def pack_records(clip_ids, res, T):
-    """Fixed-size per-clip record [b, 7+T] float32 for the all-gather."""
-    cols = [torch.as_tensor(clip_ids, device=res["pred_class"].device).float()]
-    cols += [res[k].float() for k in RECORD_FIELDS[1:]]
-    rec = torch.stack(cols, dim=1)
-    return torch.cat([rec, res["time_mask"].float()], dim=1).contiguous()
+    """Fixed-size per-clip record [b, 7+T] int32 for the all-gather: clip id,
+    pred_class, target as integers; the four scores and sigma(mask)[T] as bit-cast float32."""
+    dev = res["pred_class"].device
+    ints = [torch.as_tensor(clip_ids, device=dev).to(torch.int32)]
+    ints += [res[k].to(torch.int32) for k in RECORD_INT_FIELDS[1:]]
+    flt = torch.stack([res[k].float() for k in RECORD_FLOAT_FIELDS], dim=1)
+    flt = torch.cat([flt, res["time_mask"].float()], dim=1).contiguous()
+    return torch.cat([torch.stack(ints, dim=1), flt.view(torch.int32)], dim=1).contiguous()
 
 
 def unpack_record(row, T):
-    d = {k: row[i].item() for i, k in enumerate(RECORD_FIELDS)}
-    for k in ("clip_id", "pred_class", "target"):
-        d[k] = int(d[k])
-    d["time_mask"] = row[len(RECORD_FIELDS):len(RECORD_FIELDS) + T].cpu().numpy()
+    row = row.detach().cpu().contiguous()
+    ni = len(RECORD_INT_FIELDS)
+    d = {k: int(row[i]) for i, k in enumerate(RECORD_INT_FIELDS)}
+    f = row[ni:].view(torch.float32)
+    for i, k in enumerate(RECORD_FLOAT_FIELDS):
+        d[k] = float(f[i])
+    nf = len(RECORD_FLOAT_FIELDS)
+    d["time_mask"] = f[nf:nf + T].numpy().copy()
     return d

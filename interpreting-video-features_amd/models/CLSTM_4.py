@@ -67,6 +67,15 @@ class Model(torch.nn.Module):
         print("shape of FC is: ", self.endFC)
         self.sm = torch.nn.Softmax(dim=1)
 
+    def _out_step(self):
+        """The reference classifies `output[-1]`: the LAST effective step the unrolled loop actually
+        reached, i.e. the largest entry below `step` (convolution_lstm.py:129-130); with none the
+        list is empty and `output[-1]` raises IndexError."""
+        reached = [s for s in self.effective_step if 0 <= s < self.step]
+        if not reached:
+            raise IndexError("list index out of range")
+        return max(reached)
+
     def refresh(self):
         self._weights_version += 1
 
@@ -101,7 +110,7 @@ class Model(torch.nn.Module):
                                          layers=self.lstm_layers, kernel=self.c_kernel_size[0],
                                          stride=self.conv_stride, softmax=bool(self.add_softmax),
                                          batch_norm=bool(self.batch_normalization),
-                                         out_step=max(self.effective_step), device=x.device)
+                                         out_step=self._out_step(), device=x.device)
             ent = [-1, eng]
             self._engine_cache[key] = ent
         if ent[0] != self._weights_version:

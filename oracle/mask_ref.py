@@ -167,7 +167,7 @@ def search_clip(seq, score_fn, lam1, lam2, N, mask_type='freeze', lr=0.2, init=N
     with torch.no_grad():
         rev = float(score_fn(perturb_sequence(seq, final, 'reverse')))  # :234-235
     return dict(traj=torch.tensor(traj), mask=final, raw_mask=tm.detach().clone(),
-                freeze_score=float(score) if score is not None else float('nan'),
+                freeze_score=float(score.detach()) if score is not None else float('nan'),
                 reverse_score=rev, init=info)
 
 

@@ -43,3 +43,37 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def ranking_consistent(rank_got, mask_want, tol):
+    """A frame ranking (stable argsort of -mask) is an integer output, bit-exact where the mask
+    separates the frames; frames whose reference mask values differ by less than `tol` (exact
+    ties up to rounding: e.g. the interior of a run in a 'reverse' search, which only the
+    regulariser moves) may come in any order.  True iff `rank_got` is a permutation that sorts
+    `mask_want` non-increasingly up to `tol`."""
+    rank_got = np.asarray(rank_got).astype(np.int64)
+    mask_want = np.asarray(mask_want, dtype=np.float64)
+    if sorted(rank_got.tolist()) != list(range(mask_want.size)):
+        return False
+    v = mask_want[rank_got]
+    return bool(np.all(v[:-1] >= v[1:] - tol))
+
+
+def rel_err_elem(a, b, floor):
+    """max over elements of |a-b| / max(|b|, floor): every entry against its own magnitude."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def note(msg):
+    """Measured error figures: printed (pytest -s) and appended to gpurun_out/parity_measured.log,
+    the file the round's profiles/rNN_parity_measured.txt is copied from."""
+    print("[parity]", msg)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.log"), "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass

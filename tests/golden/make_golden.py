@@ -183,13 +183,13 @@ def gen_units():
 
 
 # ---------------------------------------------------------------- whole I3D
-def _i3d(kth=False, T=16, softmax=1):
+def _i3d(kth=False, T=16, softmax=1, sml=""):
     if kth:
         m = I3D_doubled_kth.Model(6, last_stride=1, stride_mod_layers="", finalTimeLength=T // 8,
                                   softMax=softmax).eval()
         sd = R.i3d_state_dict(num_classes=6, tag='i3d_kth')
     else:
-        m = I3D_doubled.Model(174, last_stride=1, stride_mod_layers="", softMax=softmax).eval()
+        m = I3D_doubled.Model(174, last_stride=1, stride_mod_layers=sml, softMax=softmax).eval()
         sd = R.i3d_state_dict(num_classes=174)
     m.load_state_dict(R.to_torch(sd))
     return m
@@ -289,7 +289,7 @@ def gen_gradcam():
 
 
 # ---------------------------------------------------------------- search
-def _ref_search(model, x, target, lam1, lam2, N, T):
+def _ref_search(model, x, target, lam1, lam2, N, T, mask_type='freeze', every=1):
     """Harness around the reference's own mask.py + model following
     FindMasksComparison_I3D_smth.py:188-235 (the published driver cannot run,
     SURVEY.md F8).  init_mask is restated device-agnostically because
@@ -305,7 +305,7 @@ def _ref_search(model, x, target, lam1, lam2, N, T):
             nm = torch.ones(T)
             nm[:i] = 0
             nm[-i:] = 0
-            c = score_fn(ref_mask.perturb_sequence(x, nm, perturbation_type='freeze'))
+            c = score_fn(ref_mask.perturb_sequence(x, nm, perturbation_type=mask_type))
             r = (orig - c) / (orig - full)
             cen.append(float(c))
             ratios.append(float(r))
@@ -320,7 +320,7 @@ def _ref_search(model, x, target, lam1, lam2, N, T):
         mc = torch.sigmoid(tm)
         l1 = lam1 * torch.sum(torch.abs(mc))
         tv = lam2 * ref_mask.calc_tv_norm(mc, p=3, q=3)
-        cl = model(ref_mask.perturb_sequence(x, mc, perturbation_type='freeze'))[0, target]
+        cl = model(ref_mask.perturb_sequence(x, mc, perturbation_type=mask_type))[0, target]
         loss = l1 + tv + cl
         opt.zero_grad()
         loss.backward()
@@ -328,12 +328,15 @@ def _ref_search(model, x, target, lam1, lam2, N, T):
             g0 = tm.grad.numpy().copy()
         opt.step()
         traj.append([loss.item(), l1.item(), tv.item(), cl.item()])
-        print('  iter', n, traj[-1], flush=True)
+        if n % every == 0:
+            print('  iter', n, traj[-1], flush=True)
     final = torch.sigmoid(tm.detach())
     with torch.no_grad():
         rev = model(ref_mask.perturb_sequence(x, final, perturbation_type='reverse'))[0, target]
     return dict(full=float(full), orig=float(orig), central=np.array(cen), ratios=np.array(ratios),
                 init=init.numpy(), traj=np.array(traj), mask=final.numpy(), grad0=g0,
+                raw=tm.detach().numpy().copy(),
+                ranking=torch.argsort(-final, stable=True).numpy(),
                 freeze_score=traj[-1][3], reverse_score=float(rev))
 
 
@@ -364,6 +367,161 @@ def gen_search():
     for k, v in r.items():
         out[f'c1_{k}'] = np.asarray(v)
     save('search', **out)
+
+
+def _clstm(C=1):
+    c = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=C, conv_kernel_size=(5, 5),
+                      lstm_layers=2, step=32, image_size=(160, 120), conv_stride=2,
+                      effective_step=[7, 15, 23, 31], add_softmax=True).eval()
+    c.load_state_dict(R.to_torch(R.clstm_state_dict(channels=C, tag=f'clstm{C}')))
+    for p in c.parameters():
+        p.requires_grad_(False)
+    return c
+
+
+def gen_search_long():
+    """The reference's FULL searches: N=300 on I3D S16 (smth:119), N=100 on CLSTM_4 and on
+    I3D-KTH (KTH:118) -- trajectory, final mask, ranking, reverse score."""
+    out = {}
+    c = _clstm(1)
+    xc = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0)[None]
+    with torch.no_grad():
+        tc = int(torch.argmax(c(xc)[0]))
+    r = _ref_search(c, xc, tc, 0.02, 0.04, 100, 32, every=25)
+    out['c1_target'] = np.array(tc)
+    for k, v in r.items():
+        out[f'c1_{k}'] = np.asarray(v)
+    save('search_long', **out)            # checkpoint: the I3D legs take minutes
+    m = _i3d(True, T=32)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.from_numpy(R.clip(23, 3, 32, 120, 160))[None]
+    with torch.no_grad():
+        target = int(torch.argmax(m(x)[0]))
+    r = _ref_search(m, x, target, 0.02, 0.04, 100, 32, every=10)
+    out['k32_target'] = np.array(target)
+    for k, v in r.items():
+        out[f'k32_{k}'] = np.asarray(v)
+    save('search_long', **out)
+    m = _i3d(False)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.from_numpy(R.clip(21))[None]
+    with torch.no_grad():
+        target = int(torch.argmax(m(x)[0]))
+    r = _ref_search(m, x, target, 0.01, 0.02, 300, 16, every=10)
+    out['s16_target'] = np.array(target)
+    for k, v in r.items():
+        out[f's16_{k}'] = np.asarray(v)
+    save('search_long', **out)
+
+
+def gen_search_reverse():
+    """temporalMaskType='reverse' (smth:121,202): the loop perturbs with the reverse
+    operator, which is differentiable in the mask entries of a run (mask.py:49-56)."""
+    out = {}
+    c = _clstm(1)
+    xc = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0)[None]
+    with torch.no_grad():
+        tc = int(torch.argmax(c(xc)[0]))
+    r = _ref_search(c, xc, tc, 0.02, 0.04, 30, 32, mask_type='reverse', every=10)
+    out['c1_target'] = np.array(tc)
+    for k, v in r.items():
+        out[f'c1_{k}'] = np.asarray(v)
+    m = _i3d(False)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.from_numpy(R.clip(21))[None]
+    with torch.no_grad():
+        target = int(torch.argmax(m(x)[0]))
+    r = _ref_search(m, x, target, 0.01, 0.02, 8, 16, mask_type='reverse')
+    out['s16_target'] = np.array(target)
+    for k, v in r.items():
+        out[f's16_{k}'] = np.asarray(v)
+    save('search_reverse', **out)
+
+
+def gen_i3d_s32():
+    """BASELINE configs[4] geometry: [1,3,32,224,224] through I3D_doubled.Model(174, last_stride=1,
+    stride_mod_layers="none") -- no endpoint matches, head window [4,7,7] -- forward,
+    backward and GradCamVideo."""
+    out = {}
+    tag = 's32'
+    m = _i3d(False, sml="none")
+    x = torch.from_numpy(R.clip(13, 3, 32, 224, 224))[None].requires_grad_()
+    acts = {}
+    hooks = [m._modules[n].register_forward_hook(
+        (lambda n: (lambda mod, i, o: acts.__setitem__(n, o)))(n))
+        for n in I3D_doubled.Model.VALID_ENDPOINTS if n in m._modules]
+    m.softMax = False
+    with torch.no_grad():
+        logits = m(x)
+    m.softMax = 1
+    y = m(x)
+    for h in hooks:
+        h.remove()
+    assert tuple(y.shape) == (1, 174), y.shape
+    target = int(torch.argmax(y[0]))
+    feat = acts['Mixed_5c']
+    feat.retain_grad()
+    y[0, target].backward()
+    out[f'{tag}_logits'] = logits.detach().numpy()
+    out[f'{tag}_probs'] = y.detach().numpy()
+    out[f'{tag}_target'] = np.array(target)
+    for n, a in acts.items():
+        out[f'{tag}_norm_{n}'] = np.array(float(a.detach().double().norm()))
+    f = feat.detach().numpy().ravel()
+    fi = sample_idx(f'g/i3d/{tag}/feat', f.size)
+    out[f'{tag}_feat_idx'] = fi
+    out[f'{tag}_feat_val'] = f[fi]
+    out[f'{tag}_feat_shape'] = np.array(feat.shape)
+    out[f'{tag}_dfeat_val'] = feat.grad.numpy().ravel()[fi]
+    dx = x.grad.numpy().ravel()
+    di = sample_idx(f'g/i3d/{tag}/dx', dx.size, 4096)
+    out[f'{tag}_dx_idx'] = di
+    out[f'{tag}_dx_val'] = dx[di]
+    out[f'{tag}_dx_norm'] = np.array(float(np.linalg.norm(dx.astype(np.float64))))
+    out[f'{tag}_dx_sum_per_frame'] = x.grad.numpy()[0].astype(np.float64).sum(axis=(0, 2, 3))
+    # Grad-CAM at S32 (Mixed_5c [1,1024,4,7,7] -> [32,224,224]) and a 3-iteration search
+    xg = torch.from_numpy(R.clip(13, 3, 32, 224, 224))[None]
+    for per_frame in (True, False):
+        gc = ref_gc.GradCamVideo(model=m, target_layer_names=['Mixed_5c'], class_dict=None,
+                                 use_cuda=False, input_spatial_size=(224, 224),
+                                 normalizePerFrame=per_frame, archType="I3D")
+        cam, output = gc(xg, None)
+        t = 'pf' if per_frame else 'glob'
+        out[f'gc_{t}_output'] = output.detach().numpy()
+        out[f'gc_{t}_cam_small'] = cam[:, ::8, ::8]
+        out[f'gc_{t}_cam_shape'] = np.array(cam.shape)
+        out[f'gc_{t}_cam_sum'] = np.array(cam.astype(np.float64).sum())
+    for p in m.parameters():
+        p.requires_grad_(False)
+    r = _ref_search(m, xg, target, 0.01, 0.02, 3, 32)
+    for k, v in r.items():
+        out[f'srch_{k}'] = np.asarray(v)
+    save('i3d_s32', **out)
+
+
+def gen_gradcam_k32():
+    """GradCamVideo on I3D-KTH as FindMasksComparison_I3D_KTH.py:315-327 calls it:
+    input_spatial_size=(160,120), Mixed_5c [1,1024,4,4,5] -> [32,120,160]."""
+    out = {}
+    m = _i3d(True, T=32)
+    x = torch.from_numpy(R.clip(11, 3, 32, 120, 160))[None]
+    for per_frame in (True, False):
+        gc = ref_gc.GradCamVideo(model=m, target_layer_names=['Mixed_5c'], class_dict=None,
+                                 use_cuda=False, input_spatial_size=(160, 120),
+                                 normalizePerFrame=per_frame, archType="I3D")
+        cam, output = gc(x, None)
+        t = 'pf' if per_frame else 'glob'
+        out[f'{t}_output'] = output.detach().numpy()
+        out[f'{t}_cam_small'] = cam[:, ::4, ::4]
+        out[f'{t}_cam_shape'] = np.array(cam.shape)
+        out[f'{t}_cam_sum'] = np.array(cam.astype(np.float64).sum())
+    cam, output = gc(x, 3)
+    out['idx3_cam_small'] = cam[:, ::4, ::4]
+    out['idx3_weights'] = np.mean(gc.extractor.get_gradients()[-1].numpy(), axis=(2, 3, 4))[0]
+    save('gradcam_k32', **out)
 
 
 def gen_ingest():
@@ -412,7 +570,8 @@ def gen_ingest():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest']
+    which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest',
+                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

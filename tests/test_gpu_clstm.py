@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import note, ranking_consistent, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -109,3 +109,77 @@ def test_clstm_other_geometries_match_oracle(C, T, H, W, hidden, kernel, stride)
     s, dx = eng.backward(B, target=[1, 2])
     assert abs(float(s[0]) - float(y[0, 1].detach())) < 1e-5
     assert rel_err(dx[0].cpu().numpy(), g0[0].numpy()) < 2e-3
+
+
+def test_clstm_full_length_search(golden):
+    """N=100, lam 0.02/0.04 (KTH:105-118): the whole trajectory, final mask, ranking, reverse score."""
+    import ivf_recipe as R
+    g = golden('search_long')
+    eng = _engine(1, B=1)
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None].cuda()
+    target = int(g['c1_target'])
+    raw = torch.from_numpy(g['c1_init'])[None].cuda().contiguous()
+    traj, _ = eng.search(x, [target], raw, 0.02, 0.04, 100)
+    traj = traj[:, 0].cpu().numpy()
+    ref = g['c1_traj']
+    rel = np.abs(traj - ref) / np.abs(ref)
+    final = torch.sigmoid(raw)[0].cpu().numpy()
+    dmask = float(np.max(np.abs(final - g['c1_mask'])))
+    note(f"full search clstm N=100: trajectory rel err max {rel.max():.2e} last {rel[-1].max():.2e}; "
+         f"final mask max|d| {dmask:.2e}")
+    assert rel.max() < 1e-2 and rel[-1].max() < 1e-2
+    assert dmask < 1e-2
+    assert np.array_equal(final > 0.5, g['c1_mask'] > 0.5)
+    rank = np.argsort(-final, kind='stable')
+    if np.min(np.diff(np.sort(g['c1_mask']))) > 2 * dmask:
+        assert np.array_equal(rank, g['c1_ranking'])
+    else:
+        assert ranking_consistent(rank, g['c1_mask'], 2 * dmask + 1e-7)
+    rev = eng.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
+    assert abs(float(rev) - float(g['c1_reverse_score'])) < 1e-3
+
+
+def test_clstm_reverse_mask_search(golden):
+    """temporalMaskType='reverse': 30 iterations through the reverse operator vs the reference harness."""
+    import ivf_recipe as R
+    import ivf_search
+    g = golden('search_reverse')
+    eng = _engine(1, B=1)
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None].cuda()
+    target = int(g['c1_target'])
+    probs = eng.forward(x)
+    tgt = torch.tensor([target], dtype=torch.int32, device='cuda')
+    raw, info = ivf_search.init_masks_central(eng, x, tgt, probs[0, target][None], 0.9, 'reverse')
+    assert abs(float(info['full'][0]) - float(g['c1_full'])) < 1e-5     # the fully FROZEN clip (mask.py:123-128)
+    assert np.array_equal(raw[0].cpu().numpy(), g['c1_init'])
+    traj, _ = eng.search(x, [target], raw, 0.02, 0.04, 30, mode='reverse')
+    got, ref = traj[:, 0].cpu().numpy(), g['c1_traj']
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-2
+    final = torch.sigmoid(raw)[0].cpu().numpy()
+    assert np.max(np.abs(final - g['c1_mask'])) < 2e-3
+    assert ranking_consistent(np.argsort(-final, kind='stable'), g['c1_mask'], 5e-3)
+    # whole MaskSearch with mask_type='reverse' reproduces the same init + loop
+    res = ivf_search.MaskSearch(eng, 0.02, 0.04, 30, "reverse", do_gradcam=False).run(x, [target], want_traj=True)
+    assert torch.equal(res["traj"][:, 0].cpu(), traj[:, 0].cpu())
+
+
+def test_clstm_out_step_is_last_effective_step_reached():
+    """output[-1] of the reference is the largest effective step BELOW `step`
+    (convolution_lstm.py:129-130): step=8 with effective_step=[4,8,12,15] classifies step 4."""
+    import ivf_recipe as R
+    from models import CLSTM_4
+    from oracle import clstm_ref
+    sd_np = R.clstm_state_dict(num_classes=6, hidden=4, channels=1, kernel=5, layers=2, image_size=(64, 48),
+                               conv_stride=2, tag='clstm_os')
+    m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=1, conv_kernel_size=(5, 5), lstm_layers=2, step=8,
+                      image_size=(64, 48), conv_stride=2, effective_step=[4, 8, 12, 15], add_softmax=True)
+    m.load_state_dict(R.to_torch(sd_np))
+    m = m.cuda().eval()
+    x = torch.from_numpy(R.clip(5, 1, 8, 48, 64) / 255.0).float()[None]
+    y = m(x.cuda())
+    want = clstm_ref.forward(x, R.to_torch(sd_np), steps=8, effective_step=(4, 8, 12, 15), add_softmax=True)
+    assert rel_err(y.detach().cpu().numpy(), want.numpy()) < 1e-4
+    m2 = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=1, conv_kernel_size=(5, 5), lstm_layers=2, step=3,
+                       image_size=(64, 48), conv_stride=2, effective_step=[4, 8], add_softmax=True).cuda().eval()
+    with pytest.raises(IndexError):
+        m2(torch.zeros(1, 1, 3, 48, 64).cuda())          # the reference's output[-1] on an empty list

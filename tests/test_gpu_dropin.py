@@ -143,3 +143,115 @@ def test_find_masks_class_filter_empty(model, tmp_path, monkeypatch):
     assert masks == []
     files = list((tmp_path / "results").glob("allTimeMaskResults_*"))
     assert len(files) == 1 and pk.load(open(files[0], "rb")) == []
+
+
+# ------------------------------------------------------------------ round 2
+def test_snap_values_vs_reference(golden):
+    """mask.py:5-10 against the reference's own output (mask_ops.npz snap_in/snap_out/snap_p):
+    the caller's mask is snapped IN PLACE and the frozen clip uses the snapped values."""
+    import ivf_recipe as R
+    import mask
+    g = golden('mask_ops')
+    m = torch.from_numpy(g['snap_in'].copy()).cuda()
+    xs = torch.from_numpy(R.uniform('g/snap/x', (1, 3, 16, 4, 4), 0, 255)).cuda()
+    p = mask.perturb_sequence(xs, m, 'freeze', snap_values=True)
+    assert np.array_equal(m.cpu().numpy(), g['snap_out'])            # integer-valued output: bit-exact
+    assert np.array_equal(p.cpu().numpy(), g['snap_p'])
+
+
+@pytest.mark.parametrize("backbone", ["i3d", "clstm"])
+def test_kth_driver_find_masks(backbone, tmp_path, monkeypatch):
+    """FindMasksComparison_I3D_KTH.find_masks (KTH arity with `ita`, KTH:126-127) on both backbones
+    (KTH:50-58): KTH result-file names (KTH:372-378), un-cast original_score_guess, [32,120,160] maps."""
+    import FindMasksComparison_I3D_KTH as drv
+    import ivf_find_masks
+    import ivf_recipe as R
+    monkeypatch.chdir(tmp_path)
+    if backbone == "i3d":
+        from models import I3D_doubled_kth
+        m = I3D_doubled_kth.Model(6, last_stride=1, stride_mod_layers="", finalTimeLength=4, softMax=1)
+        m.load_state_dict(R.to_torch(R.i3d_state_dict(num_classes=6, tag='i3d_kth')))
+    else:
+        from models import CLSTM_4
+        m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=3, conv_kernel_size=(5, 5), lstm_layers=2,
+                          step=32, image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31])
+        m.load_state_dict(R.to_torch(R.clstm_state_dict(channels=3, tag='clstm3')))
+    m = m.cuda().eval()
+    loader = ivf_find_masks.SyntheticLoader(2, 2, (3, 32, 120, 160), 6, first_id=7)
+    cfg = {"batch_size": 2, "gradCamType": "guessed"}
+    masks = drv.find_masks(loader, m, cfg, 0.02, 0.04, 4, 1, "central", "freeze", classOI=None,
+                           doGradCam=(backbone == "i3d"), runTempMask=True, verbose=False)
+    assert len(masks) == 2 and masks[0].shape == (32,)
+    tm = pickle.load(open(tmp_path / "results" / "I3d_KTH_allTimeMaskResults_original_run0.p", "rb"))
+    gc = pickle.load(open(tmp_path / "results" / "I3d_KTH_allGradCamResults_original_run0.p", "rb"))
+    assert len(tm) == 2 and tm[0]['time_mask'].shape == (32,) and tm[0]['video_id'] == "7"
+    assert isinstance(tm[0]['original_score_guess'], float) and tm[0]['original_score_guess'] > 0   # no int() cast (KTH:274)
+    if backbone == "i3d":
+        assert len(gc) == 2 and gc[0]['GCHeatMap'].shape == (32, 120, 160) and gc[0]['GCHeatMap'].dtype == np.float32
+    else:
+        assert gc == []
+
+
+def test_sharded_searches_equal_unsharded():
+    """SURVEY 8e on one GPU: the clip_id % 2 shards run one after the other (own plans, rank 0's tuning
+    vector installed through get_tuning/set_tuning, as bench.py broadcasts it), pack_records -> merge
+    must equal the unsharded run bit for bit."""
+    import ivf_engine
+    import ivf_recipe as R
+    import ivf_search
+    import ivf_shard
+    T, n = 16, 4
+    sd = R.i3d_state_dict(num_classes=174)
+    ids = list(range(n))
+
+    def run(eng, clip_ids):
+        x = torch.from_numpy(np.stack([R.clip(c % 16) for c in clip_ids])).cuda()
+        s = ivf_search.MaskSearch(eng, 0.01, 0.02, 6, "freeze", do_gradcam=False)
+        res = s.run(x, [R.label(c, 174) for c in clip_ids])
+        return ivf_search.pack_records(clip_ids, res, T)
+
+    full = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=n, softmax=True)
+    full.load_state_dict(sd)                       # autotunes at batch n ("rank 0")
+    want = ivf_shard.gather_records(run(full, ids))
+    tuning = full.get_tuning()
+    parts = []
+    for rank in range(2):
+        eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=n // 2, softmax=True)
+        eng.load_state_dict(sd, autotune=False)
+        eng.set_tuning(tuning)
+        parts.append(run(eng, ivf_shard.shard_ids(ids, rank, 2)))
+    got = ivf_shard.gather_records(torch.cat(parts))
+    assert got.dtype == torch.int32 and torch.equal(got, want)
+    d = ivf_search.unpack_record(got[3], T)
+    assert d["clip_id"] == 3 and d["time_mask"].shape == (T,) and 0 < d["freeze_score"] < 1
+
+
+def test_drivers_run_on_a_jpeg_folder(tmp_path, monkeypatch):
+    """main() of the smth driver on a JPEG clip folder laid out as the reference's PicDatabase expects
+    (data_parser.py:121-131), decoded on the host and cast/permuted on the device."""
+    from PIL import Image
+    import FindMasksComparison_I3D_smth as drv
+    import ivf_ingest
+    import ivf_recipe as R
+    monkeypatch.chdir(tmp_path)
+    root = tmp_path / "data" / "validation"
+    for cls, cid in ((3, 101), (5, 202)):
+        d = root / str(cls) / str(cid)
+        d.mkdir(parents=True)
+        clip = R.clip(cid % 16).astype(np.uint8)                      # [3,T,H,W]
+        for t in range(16):
+            Image.fromarray(np.ascontiguousarray(clip[:, t].transpose(1, 2, 0)), 'RGB').save(
+                d / "frame{:02d}.jpg".format(t + 1), quality=90)
+    loader = ivf_ingest.JpegFolderLoader(str(root), clip_size=16, batch_size=2, layout="smth")
+    assert len(loader) == 1
+    seq, label, ids = next(iter(loader))
+    assert seq.is_cuda and tuple(seq.shape) == (2, 3, 16, 224, 224) and seq.dtype == torch.float32
+    assert sorted(label.tolist()) == [3, 5] and sorted(ids) == ["101", "202"]
+    assert float(seq.min()) >= 0 and float(seq.max()) <= 255 and torch.equal(seq, seq.round())
+    cfg = tmp_path / "cfg.py"
+    cfg.write_text("config = " + repr({
+        "conv_model": "models.I3D_doubled", "num_classes": 174, "batch_size": 2, "clip_size": 16,
+        "data_folder": str(tmp_path / "data"), "num_workers": 0, "shuffle": 0}))
+    drv.main(["-c", str(cfg), "--msl", "", "--optIter", "3", "--subDir", "jpg"])
+    tm = pickle.load(open(tmp_path / "results" / "allTimeMaskResults_jpg_None_.p", "rb"))
+    assert sorted(r['video_id'] for r in tm) == ["101", "202"] and sorted(r['true_class'] for r in tm) == [3, 5]

@@ -73,3 +73,24 @@ def test_no_cpu_fallback():
     m = I3D_doubled.Model(10, stride_mod_layers="", softMax=1).eval()
     with pytest.raises(L.IvfError):
         m(torch.zeros(1, 3, 16, 224, 224))
+
+
+def test_jpeg_folder_listing_follows_the_reference_layouts(tmp_path):
+    """Host logic of the clip loader (no device needed): PicDatabase / KTHImLoader folder layouts,
+    drop_last batching (smth:71-77, KTH:73-78)."""
+    import ivf_ingest
+    smth = tmp_path / "smth"
+    for cls, clips in ((7, (11, 12, 13)), (9, (21,))):
+        for c in clips:
+            (smth / str(cls) / str(c)).mkdir(parents=True)
+    ld = ivf_ingest.JpegFolderLoader(str(smth), clip_size=16, batch_size=3, layout="smth")
+    assert sorted((lab, cid) for _, lab, cid in ld.items) == [(7, "11"), (7, "12"), (7, "13"), (9, "21")]
+    assert len(ld) == 1                                   # drop_last
+    assert len(ivf_ingest.JpegFolderLoader(str(smth), 16, 3, "smth", drop_last=False)) == 2
+    kth = tmp_path / "kth"
+    for i in range(5):
+        (kth / str(i)).mkdir(parents=True)
+    ld = ivf_ingest.JpegFolderLoader(str(kth), clip_size=32, batch_size=2, layout="kth")
+    assert [os.path.basename(f) for f, _, _ in ld.items] == ["0", "1", "2", "3", "4"] and len(ld) == 2
+    with pytest.raises(FileNotFoundError):
+        ivf_ingest.JpegFolderLoader(str(tmp_path / "missing"), 16, 2, "smth")

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import ivf_recipe as R
-from conftest import rel_err
+from conftest import ranking_consistent, rel_err
 from oracle import clstm_ref, gradcam_ref, i3d_ref, ingest_ref, mask_ref
 
 torch.set_num_threads(8)
@@ -163,3 +163,108 @@ def test_ingest_matches_reference_loaders(golden):
     assert np.array_equal(x, g['kth_data']) and np.array_equal(x, g['smth_data'])
     cl = ingest_ref.to_channels_last(frames, 4)
     assert np.array_equal(cl[..., :3].transpose(3, 0, 1, 2), x) and not cl[..., 3].any()
+
+
+# ------------------------------------------------------------------ round-2 fixtures
+def test_i3d_s32_branch_matches_reference_model(golden):
+    """stride_mod_layers="none", head window [4,7,7] (SURVEY F13 / BASELINE configs[4]): the
+    oracle branch the GPU tests lean on, against the reference model's own output."""
+    g = golden('i3d_s32')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(13, 3, 32, 224, 224))[None].requires_grad_()
+    eps = {}
+    feat = i3d_ref.features(x, sd, "none", 1, endpoints=eps)
+    feat.retain_grad()
+    logits, probs = i3d_ref.head(feat, sd, (4, 7, 7), True)
+    assert list(feat.shape) == g['s32_feat_shape'].tolist()
+    assert rel_err(logits.detach().numpy(), g['s32_logits']) < 1e-5
+    assert rel_err(probs.detach().numpy(), g['s32_probs']) < 1e-5
+    t = int(probs[0].argmax())
+    assert t == int(g['s32_target'])
+    for n, a in eps.items():
+        assert abs(float(a.detach().double().norm()) - float(g[f's32_norm_{n}'])) < 1e-5 * float(g[f's32_norm_{n}'])
+    probs[0, t].backward()
+    assert rel_err(feat.grad.numpy().ravel()[g['s32_feat_idx']], g['s32_dfeat_val']) < 1e-4
+    assert rel_err(x.grad.numpy().ravel()[g['s32_dx_idx']], g['s32_dx_val']) < 1e-3
+    xg = x.detach()
+    for tag, pf in (('pf', True), ('glob', False)):
+        cam, out, _ = gradcam_ref.gradcam_i3d(xg, sd, None, pool_kernel=(4, 7, 7), normalize_per_frame=pf,
+                                              stride_mod_layers="none", last_stride=1)
+        assert list(cam.shape) == g[f'gc_{tag}_cam_shape'].tolist() == [32, 224, 224]
+        assert rel_err(out.numpy(), g[f'gc_{tag}_output']) < 1e-5
+        assert np.allclose(cam[:, ::8, ::8], g[f'gc_{tag}_cam_small'], atol=2e-5, equal_nan=True)
+
+
+def test_gradcam_k32_matches_reference(golden):
+    """GradCamVideo as the KTH driver calls it (KTH:315-327): input_spatial_size=(160,120),
+    Mixed_5c [1,1024,4,4,5] -> [32,120,160]."""
+    g = golden('gradcam_k32')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=6, tag='i3d_kth'))
+    x = torch.from_numpy(R.clip(11, 3, 32, 120, 160))[None]
+    for tag, pf in (('pf', True), ('glob', False)):
+        cam, out, _ = gradcam_ref.gradcam_i3d(x, sd, None, pool_kernel=(4, 4, 5), width=160, height=120,
+                                              normalize_per_frame=pf)
+        assert list(cam.shape) == g[f'{tag}_cam_shape'].tolist() == [32, 120, 160]
+        assert rel_err(out.numpy(), g[f'{tag}_output']) < 1e-5
+        assert np.allclose(cam[:, ::4, ::4], g[f'{tag}_cam_small'], atol=2e-5, equal_nan=True)
+    # (the fixture's explicit-index call used the globally normalised instance)
+    cam, out, ex = gradcam_ref.gradcam_i3d(x, sd, 3, pool_kernel=(4, 4, 5), width=160, height=120,
+                                           normalize_per_frame=False)
+    assert rel_err(ex['weights'], g['idx3_weights']) < 1e-4
+    assert np.allclose(cam[:, ::4, ::4], g['idx3_cam_small'], atol=2e-5, equal_nan=True)
+
+
+def test_resize_bilinear_against_two_independent_implementations():
+    """cv2.resize (INTER_LINEAR) is absent here, so the restatement is cross-checked against two
+    independent bilinear up-scalers with OpenCV's convention (half-pixel centres, edge clamp):
+    torch F.interpolate(align_corners=False) and PIL mode-'F' BILINEAR, at the three geometries
+    Grad-CAM uses (7x7 -> 224x224, 4x5 -> 120x160, non-square)."""
+    import torch.nn.functional as F
+    from PIL import Image
+    for (sh, sw, dh, dw) in ((7, 7, 224, 224), (4, 5, 120, 160), (7, 7, 120, 160)):
+        src = R.uniform(f't/resize/{sh}x{sw}', (sh, sw), 0, 3)
+        ours = gradcam_ref.resize_bilinear(src, dw, dh)
+        ti = F.interpolate(torch.from_numpy(src)[None, None], size=(dh, dw), mode='bilinear',
+                           align_corners=False)[0, 0].numpy()
+        pil = np.asarray(Image.fromarray(src, mode='F').resize((dw, dh), Image.BILINEAR))
+        assert ours.shape == (dh, dw)
+        assert np.max(np.abs(ours - ti)) < 2e-6 * 3
+        assert np.max(np.abs(ours - pil)) < 2e-6 * 3
+
+
+def test_reverse_mask_search_matches_reference(golden):
+    """temporalMaskType='reverse': init_mask scores the fully FROZEN clip whatever the mask type
+    (mask.py:123-128), the loop optimises through the reverse operator (mask.py:49-56)."""
+    g = golden('search_reverse')
+    sd = R.to_torch(R.clstm_state_dict(channels=1, tag='clstm1'))
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None]
+    target = int(g['c1_target'])
+
+    def score_fn(v):
+        return clstm_ref.forward(v, sd, add_softmax=True)[0, target]
+    res = mask_ref.search_clip(x, score_fn, 0.02, 0.04, 30, 'reverse')
+    assert abs(res['init']['full'] - float(g['c1_full'])) < 1e-6
+    assert np.allclose(res['init']['central'], g['c1_central'], atol=1e-6)
+    assert np.max(np.abs(res['traj'].numpy() - g['c1_traj']) / np.abs(g['c1_traj'])) < 1e-4
+    assert np.max(np.abs(res['mask'].numpy() - g['c1_mask'])) < 1e-4
+    # the interior frames of the run move under the regulariser only and stay tied to rounding
+    assert ranking_consistent(mask_ref.frame_ranking(res['mask']).numpy(), g['c1_mask'], 1e-4)
+    assert np.array_equal(mask_ref.frame_ranking(res['mask']).numpy()[:4], g['c1_ranking'][:4])
+
+
+def test_clstm_full_length_search_matches_reference(golden):
+    """N=100 (KTH:118): the whole trajectory, final mask, ranking, scores."""
+    g = golden('search_long')
+    sd = R.to_torch(R.clstm_state_dict(channels=1, tag='clstm1'))
+    x = torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0).float()[None]
+    target = int(g['c1_target'])
+
+    def score_fn(v):
+        return clstm_ref.forward(v, sd, add_softmax=True)[0, target]
+    res = mask_ref.search_clip(x, score_fn, 0.02, 0.04, 100, 'freeze')
+    assert g['c1_traj'].shape == (100, 4)
+    assert np.max(np.abs(res['traj'].numpy() - g['c1_traj']) / np.abs(g['c1_traj'])) < 5e-4
+    assert np.max(np.abs(res['mask'].numpy() - g['c1_mask'])) < 5e-4
+    assert np.array_equal(mask_ref.frame_ranking(res['mask']).numpy(), g['c1_ranking'])
+    assert np.array_equal(res['mask'].numpy() > 0.5, g['c1_mask'] > 0.5)
+    assert abs(res['reverse_score'] - float(g['c1_reverse_score'])) < 1e-4

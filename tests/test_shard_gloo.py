@@ -12,13 +12,29 @@ import torch.multiprocessing as mp
 from conftest import PKG, ROOT
 
 
+BIG = 1 << 25      # clip ids above 2^24 are not exact in float32: records carry them as int32
+
+
 def _fake_records(ids, T=16):
-    """Deterministic stand-in for a finished search record (clip id + 6 scalars + mask)."""
-    rows = []
-    for c in ids:
-        g = torch.Generator().manual_seed(1000 + c)
-        rows.append(torch.cat([torch.tensor([float(c)]), torch.rand(6 + T, generator=g)]))
-    return torch.stack(rows) if rows else torch.empty(0, 7 + T)
+    """Deterministic stand-in for a finished search: the record ivf_search.pack_records builds."""
+    import ivf_search
+    if not ids:
+        return torch.empty(0, 7 + T, dtype=torch.int32)
+    g = torch.Generator().manual_seed(1000 + ids[0])
+    n = len(ids)
+    res = {"pred_class": torch.randint(0, 174, (n,), generator=g), "target": torch.randint(0, 174, (n,), generator=g),
+           "time_mask": torch.rand(n, T, generator=g)}
+    for k in ivf_search.RECORD_FLOAT_FIELDS:
+        res[k] = torch.rand(n, generator=g)
+    return ivf_search.pack_records([BIG + c for c in ids], res, T)
+
+
+def _all_records(n_clips, world):
+    """What a single process holding every shard would gather."""
+    import ivf_shard
+    parts = [_fake_records(ivf_shard.shard_ids(list(range(n_clips)), r, world)) for r in range(world)]
+    rec = torch.cat(parts)
+    return rec[torch.argsort(rec[:, 0].to(torch.int64), stable=True)]
 
 
 def _worker(rank, world, port, n_clips, out_dir):
@@ -32,7 +48,7 @@ def _worker(rank, world, port, n_clips, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ids = ivf_shard.shard_ids(list(range(n_clips)), rank, world)
     assert all(c % world == rank for c in ids)
-    got = ivf_shard.gather_records(_fake_records(ids))
+    got = ivf_shard.gather_records(_fake_records(ids), equal_shards=(n_clips % world == 0))
     torch.save(got, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -49,14 +65,22 @@ def _free_port():
 @pytest.mark.parametrize("world,n_clips", [(2, 8), (2, 7), (2, 1), (3, 10)])
 def test_sharded_gather_equals_single_process(world, n_clips, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), n_clips, str(tmp_path)), nprocs=world, join=True)
-    want = _fake_records(list(range(n_clips)))
+    import ivf_search
+    want = _all_records(n_clips, world)
+    assert want[:, 0].tolist() == [BIG + c for c in range(n_clips)]
     for r in range(world):
         got = torch.load(tmp_path / f"r{r}.pt")
-        assert torch.equal(got, want), f"rank {r}"
+        assert got.dtype == torch.int32 and torch.equal(got, want), f"rank {r}"
+    if n_clips:
+        d = ivf_search.unpack_record(want[-1], 16)
+        assert d["clip_id"] == BIG + n_clips - 1 and d["time_mask"].shape == (16,)
+        assert 0.0 <= d["freeze_score"] < 1.0
 
 
 def test_single_process_gather_sorts():
     import ivf_shard
-    rec = _fake_records([5, 2, 9])
+    rec = torch.cat([_fake_records([5]), _fake_records([2]), _fake_records([9])])
     out = ivf_shard.gather_records(rec)
-    assert out[:, 0].tolist() == [2.0, 5.0, 9.0]
+    assert out[:, 0].tolist() == [BIG + 2, BIG + 5, BIG + 9]
+    with pytest.raises(TypeError):
+        ivf_shard.gather_records(rec.float())
