@@ -8,6 +8,8 @@
 // No autograd: only dL/d(input) is propagated, activations are kept
 // once as the ReLU gates, Inception branches write straight into their slice of the
 // concatenated output (no torch.cat copy).
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -771,6 +773,8 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
   IVF_CHECK_HIP(hipEventCreate(&e0));
   IVF_CHECK_HIP(hipEventCreate(&e1));
   int rc = IVF_OK;
+  // IVF_TUNE_LOG=<file>: every candidate's time per layer and direction (dev measurement aid)
+  FILE* tlog = getenv("IVF_TUNE_LOG") ? fopen(getenv("IVF_TUNE_LOG"), "a") : nullptr;
   for (Op& o : net->ops) {
     if (o.type != Op::CONV) continue;
     const ConvLayer& L = net->convs[o.conv];
@@ -803,6 +807,9 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
         if (hipEventSynchronize(e1) != hipSuccess) { rc = IVF_ERR_HIP; set_error("autotune: sync failed"); break; }
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
+        if (tlog)
+          fprintf(tlog, "%s %s b=%d variant=%d ms=%.4f gflop=%.1f\n", L.name.c_str(), dir ? "bwd" : "fwd", b, ids[k],
+                  ms / reps, (dir && o.bwd_fused ? o.flops_bwd_per_clip : o.flops_per_clip) * b / 1e9);
         // a later candidate must win by 1.5 %: keeps the choice between tied tile shapes stable from run to run
         if (ms < best * (best_id == IVF_CONV_AUTO ? 1.f : 0.985f)) { best = ms; best_id = ids[k]; }
       }
@@ -810,6 +817,7 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
     }
     if (rc != IVF_OK) break;
   }
+  if (tlog) fclose(tlog);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return rc;
