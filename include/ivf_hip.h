@@ -392,6 +392,22 @@ int ivf_i3d_set_tuning(ivf_i3d_t* net, const int* variants_host);
  * channel counts; backward-data costs the same again).  SURVEY.md section 8d. */
 double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net);
 
+/* ------------------------------------------------------------------ visualisation */
+
+/* create_image_arrays, visualisation.py:96-130 (RESIZE_FLAG = 0 as in both drivers): per frame the strip
+ * original | heat-map overlay | perturbed clip, BGR uint8 [T][H][3W][3].  clip, perturbed [3,T,H,W]
+ * (RGB planes, 0..255), cam [T,H,W] in [0,1] (GradCamVideo output), lut_bgr [256][3] =
+ * cv2.COLORMAP_JET in BGR order (host-provided), frame_max: T floats of workspace.
+ * overlay = (lut[uint8(255 cam)] + original) / max over the frame, then uint8(255 .). */
+int ivf_viz_blend(const float* clip, const float* cam, const float* perturbed, const unsigned char* lut_bgr,
+                  float* frame_max, unsigned char* out, int T, int H, int W, ivf_stream_t stream);
+/* vizualize_results_on_gradcam, visualisation.py:35-64: the red (mask 1) / green (mask 0) dot row on the
+ * third panel of every frame, 255 for the frame's own dot, 150 for the others; mask_snapped [T] holds 0/1
+ * (find_temp_mask_red_dots :67-93 snaps the caller's mask first).  image_width/height: the reference's
+ * defaults are 224 whatever the frame size. */
+int ivf_viz_dots(unsigned char* img, const float* mask_snapped, int T, int H, int W3, int image_width,
+                 int image_height, ivf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement */
 
 /* HIP-event timing of the convolution launches on their own stream, sampled on every

@@ -45,7 +45,7 @@ def _unwrap(model):
 
 def find_masks_impl(dat_loader, model, hyper_params, lam1, lam2, N, temporalMaskType="freeze", classOI=None,
                     verbose=True, doGradCam=False, runTempMask=True, flavour="smth", sub_dir="run0",
-                    results_path="results/", gradcam_size=None, write_files=True, device=None):
+                    results_path="results/", gradcam_size=None, write_files=True, device=None, visualise=True):
     net = _unwrap(model)
     net.eval()                                                      # smth:145
     flt = _class_filter(classOI)
@@ -73,7 +73,9 @@ def find_masks_impl(dat_loader, model, hyper_params, lam1, lam2, N, temporalMask
                                        do_gradcam=doGradCam, run_temp_mask=runTempMask,
                                        normalize_per_frame=True, gradcam_size=gradcam_size)
         res = search.run(xs, labels[keep])
-        host = {k: v.detach().cpu() for k, v in res.items()}
+        host = {k: v.detach().cpu() for k, v in res.items() if k != "gradcam"}
+        if doGradCam:
+            host["gradcam"] = res["gradcam"].detach().cpu()
         for j, bi in enumerate(keep):
             true_class = int(labels[bi])
             pred = int(host["pred_class"][j])
@@ -96,13 +98,28 @@ def find_masks_impl(dat_loader, model, hyper_params, lam1, lam2, N, temporalMask
                                      'time_mask': tm,
                                      'original_score_guess': int(gs) if flavour == "smth" else gs,
                                      'original_score_true': cs, 'freeze_score': fz, 'reverse_score': rv})
-                masks.append(res["time_mask"][j])
+                tmask = res["time_mask"][j].clone()     # the clip's own [T] tensor, as the reference's time_mask
                 if verbose:
-                    print("resulting mask is: ", res["time_mask"][j])
+                    print("resulting mask is: ", tmask)
             if doGradCam:
                 cam_results.append({'true_class': true_class, 'pred_class': pred,
                                     'video_id': int(vid) if flavour == "smth" else vid,
                                     'GCHeatMap': host["gradcam"][j].numpy().astype(np.float32)})
+            if runTempMask and write_files and visualise:
+                # smth:296-303 / KTH:354-367: heat-map strips with the mask dot row for both perturbation
+                # types (the dot row snaps `tmask` IN PLACE, so the returned masks are the snapped ones, as
+                # in the reference), then for KTH the perturbed frames as PNGs
+                import visualisation as viz
+                if doGradCam:
+                    for kind in ("freeze", "reverse"):
+                        viz.create_image_arrays(xs, res["gradcam"][j], tmask, j, kind, d, str(vid), 0,
+                                                xs.shape[4], xs.shape[3])
+                if flavour != "smth":
+                    import mask as _mask
+                    viz.vizualize_results(xs[j], _mask.perturb_sequence(xs, tmask, temporalMaskType)[j], tmask,
+                                          rootDir=d, case=str(vid), markImgs=True, iterTest=False)
+            if runTempMask:
+                masks.append(tmask)
     if write_files:
         if flavour == "smth":                                       # smth:307-313
             tname = "allTimeMaskResults_" + sub_dir + "_" + str(classOI) + "_" + ".p"

@@ -112,6 +112,8 @@ _SIGS = {
     "ivf_i3d_autotune": (c_int, [_P, _I, _I, _P]),
     "ivf_i3d_get_tuning": (c_int, [_P, POINTER(c_int)]),
     "ivf_i3d_set_tuning": (c_int, [_P, POINTER(c_int)]),
+    "ivf_viz_blend": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ivf_viz_dots": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ivf_profile_enable": (c_int, [_I, _I]),
     "ivf_profile_disable": (c_int, []),
     "ivf_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),

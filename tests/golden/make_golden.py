@@ -524,6 +524,43 @@ def gen_gradcam_k32():
     save('gradcam_k32', **out)
 
 
+def gen_viz():
+    """Visualisation blend: the reference's create_image_arrays /
+    vizualize_results_on_gradcam themselves, with cv2 bound to stand-ins (applyColorMap = the oracle's
+    JET table, imwrite = no-op) and the module's undefined `perturb_sequence` bound to mask.py's."""
+    import tempfile
+    from oracle import viz_ref
+    cv2.applyColorMap = lambda gray, cmap: viz_ref.apply_colormap_jet(gray)
+    cv2.COLORMAP_JET = 2
+    cv2.imwrite = lambda path, img: True
+    import visualisation as ref_viz
+    ref_viz.perturb_sequence = ref_mask.perturb_sequence          # NameError at visualisation.py:115 otherwise
+    ref_viz.os.system = lambda cmd: 0                             # ImageMagick `convert`
+    out = {}
+    # A: 224-wide frames (the dot row lands on the third panel), both perturbation types
+    # B: KTH-like 160-wide frames, 32 dots: the reference keeps imageWidth=224, so most dots fall off the
+    #    480-wide strip and numpy clips them -- third panel stored, the rest as a checksum
+    for tag, (T, H, W), kinds in (('a', (8, 14, 224), ('freeze', 'reverse')), ('b', (32, 12, 160), ('freeze',))):
+        x = torch.from_numpy(R.uniform(f'g/viz/{tag}/x', (2, 3, T, H, W), 0, 255)).round()
+        cam = R.uniform(f'g/viz/{tag}/cam', (T, H, W), 0, 1).astype(np.float32)
+        cam[3] = 0.0
+        cam[5, :4] = 1.0
+        tm = torch.from_numpy(R.uniform(f'g/viz/{tag}/tm', (T,), 0, 1))
+        tm[2] = 0.5
+        for kind in kinds:
+            m = tm.clone()
+            with tempfile.TemporaryDirectory() as d:
+                img = ref_viz.create_image_arrays(x, cam, m, 1, kind, d, "tag", 0, W, H)
+            assert img.shape == (3, T, H, 3 * W) and img.dtype == np.uint8
+            if tag == 'a':
+                out[f'a_{kind}_img'] = img                        # [3,T,H,3W] uint8 BGR planes, dots included
+            else:
+                out[f'b_{kind}_panel3'] = img[..., 2 * W:]
+                out[f'b_{kind}_sum12'] = np.array(img[..., :2 * W].astype(np.int64).sum())
+            out[f'{tag}_{kind}_mask_after'] = m.numpy().copy()    # snapped in place by the dot row
+    save('viz', **out)
+
+
 def gen_ingest():
     """Clip ingest: the reference loader classes on small synthetic JPEG
     folders.  The fixture holds the JPEG bytes themselves (a few KB) and the loader output."""
@@ -571,7 +608,7 @@ def gen_ingest():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest',
-                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long']
+                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

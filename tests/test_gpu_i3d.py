@@ -74,7 +74,7 @@ def _check_forward_backward(eng, tag, shape, g, clip_id=7):
 def _modulewise_backward(eng, sd_np, shape, pool_kernel):
     # element-level threshold: fp32 MFMA is an exact fp32 FMA chain; the split-bf16 mode
     # carries ~2^-17 per product
-    thr, med_tol, frac_tol = (1e-4, 1e-6, 5e-3) if eng.math == "fp32" else (1e-3, 2e-5, 0.15)
+    thr, med_tol, frac_tol = (1e-4, 1e-6, 2e-3) if eng.math == "fp32" else (1e-3, 5e-6, 0.02)
     """Strict backward parity: for every endpoint, run the CPU oracle's module on the
     GPU's own input activation with the GPU's own upstream gradient and compare the
     downstream gradient.  Identical inputs => identical ties/gates => fp32 rounding only."""
@@ -126,13 +126,13 @@ def _modulewise_backward(eng, sd_np, shape, pool_kernel):
         # pre-activation is within rounding of 0 may flip; one flip moves up to
         # taps x Cin downstream entries.  Allow a small fraction of outliers, never a
         # systematic error: the median must sit at fp32 rounding and the L2 error stay small.
-        # (In the split-bf16 mode the two sides differ by ~1e-5, so more gates sit within
-        # rounding of zero; in the deep 4x4x5 maps one flipped unit touches many cells.)
+        # Measured (profiles/r02_parity_measured.txt): outlier fraction <= 0.0006 fp32 / 0.0063
+        # split-bf16, L2 <= 5.8e-4 / 4.1e-3; the gates sit 3x above that.
         assert bad.mean() < frac_tol, (src, float(bad.mean()))
         med = np.median(np.abs(got - refn)) / scale
         assert med < med_tol, (src, med)
         l2 = np.linalg.norm((got - refn).astype(np.float64)) / np.linalg.norm(refn.astype(np.float64))
-        assert l2 < (5e-3 if eng.math == "fp32" else 2e-2), (src, l2)
+        assert l2 < (2e-3 if eng.math == "fp32" else 1e-2), (src, l2)
         worst = max(worst, float(bad.mean()))
         stats.append((src, float(bad.mean()), float(med), float(l2)))
     w = max(stats, key=lambda t: t[1])
@@ -157,6 +157,28 @@ def test_i3d_s16_forward_backward(s16, golden):
 
 def test_i3d_k32_forward_backward(k32, golden):
     _check_forward_backward(k32, 'k32', (3, 32, 120, 160), golden('i3d'))
+
+
+def test_whole_chain_dx_cpu_vs_cpu(golden):
+    """Evidence behind the loose whole-chain d(score)/d(input) gate above: the SAME torch-CPU oracle, run
+    on this box's host cores, against the fixture the build container's CPU produced.  Any difference is
+    two fp32 CPU implementations routing max-pool near-ties / ReLU zeros differently; the figure is
+    recorded in profiles/rNN_parity_measured.txt and must itself respect the gate the GPU is held to."""
+    import ivf_recipe as R
+    from oracle import i3d_ref
+    g = golden('i3d')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(7))[None].requires_grad_()
+    probs = i3d_ref.forward(x, sd)
+    t = int(g['s16_target'])
+    probs[0, t].backward()
+    dx = x.grad.numpy()
+    sample, ref = dx.ravel()[g['s16_dx_idx']].astype(np.float64), g['s16_dx_val'].astype(np.float64)
+    l2 = np.linalg.norm(sample - ref) / np.linalg.norm(ref)
+    spf = rel_err(dx[0].astype(np.float64).sum(axis=(0, 2, 3)), g['s16_dx_sum_per_frame'])
+    note(f"whole-chain dx, torch-CPU on this host ({torch.get_num_threads()} threads) vs torch-CPU on the build "
+         f"container: sampled L2 {l2:.2e}, max {rel_err(sample, ref):.2e}, per-frame sums {spf:.2e}")
+    assert l2 < 3e-2 and rel_err(sample, ref) < 8e-2
 
 
 def test_batch_rows_independent(s16):

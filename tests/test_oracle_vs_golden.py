@@ -268,3 +268,39 @@ def test_clstm_full_length_search_matches_reference(golden):
     assert np.array_equal(mask_ref.frame_ranking(res['mask']).numpy(), g['c1_ranking'])
     assert np.array_equal(res['mask'].numpy() > 0.5, g['c1_mask'] > 0.5)
     assert abs(res['reverse_score'] - float(g['c1_reverse_score'])) < 1e-4
+
+
+def _viz_inputs(tag, T, H, W):
+    x = torch.from_numpy(R.uniform(f'g/viz/{tag}/x', (2, 3, T, H, W), 0, 255)).round()
+    cam = R.uniform(f'g/viz/{tag}/cam', (T, H, W), 0, 1).astype(np.float32)
+    cam[3] = 0.0
+    cam[5, :4] = 1.0
+    tm = torch.from_numpy(R.uniform(f'g/viz/{tag}/tm', (T,), 0, 1))
+    tm[2] = 0.5
+    return x, cam, tm
+
+
+def test_viz_blend_matches_reference(golden):
+    """oracle/viz_ref.py against what the reference's create_image_arrays +
+    vizualize_results_on_gradcam returned (JET table shared: parity unpinned for that table only)."""
+    from oracle import viz_ref
+    g = golden('viz')
+    for tag, (T, H, W), kinds in (('a', (8, 14, 224), ('freeze', 'reverse')), ('b', (32, 12, 160), ('freeze',))):
+        x, cam, tm = _viz_inputs(tag, T, H, W)
+        for kind in kinds:
+            m = tm.clone()
+            snapped = mask_ref.snap(m.clone())
+            pert = mask_ref.perturb_sequence(x, snapped, kind)[1].numpy()
+            strip = viz_ref.combine_frames(x[1].numpy(), cam, pert)                  # [T,H,3W,3]
+            img = np.ascontiguousarray(strip.transpose(3, 0, 1, 2))
+            mk = m.numpy()
+            viz_ref.draw_dots(img, mk)                                               # snaps mk in place
+            assert np.array_equal(mk, g[f'{tag}_{kind}_mask_after'])
+            if tag == 'a':
+                assert np.array_equal(img, g[f'a_{kind}_img'])
+            else:
+                assert np.array_equal(img[..., 2 * W:], g[f'b_{kind}_panel3'])
+                assert int(img[..., :2 * W].astype(np.int64).sum()) == int(g[f'b_{kind}_sum12'])
+    lut = viz_ref.jet_lut_bgr()
+    assert lut.shape == (256, 3) and lut.dtype == np.uint8
+    assert lut[0].tolist() == [143, 0, 0] and lut[255].tolist() == [0, 0, 128] and lut[128].tolist()[1] == 255
