@@ -345,6 +345,11 @@ typedef struct {
   int batch_norm;        /* the single shared BatchNorm2d (convolution_lstm.py:85,123) */
   int out_step;          /* step whose pooled top-layer output feeds endFC: the LAST effective
                             step (CLSTM_4.py:78-80 with use_entire_seq=False) */
+  /* use_entire_seq=True (CLSTM_4.py:73-76): endFC reads the pooled top-layer outputs of ALL the
+   * effective steps reached, concatenated per clip in step order (n_out_steps * feat inputs);
+   * n_out_steps == 0 selects the single out_step above. */
+  int n_out_steps;
+  int out_steps[16];
 } ivf_clstm_config;
 
 typedef struct ivf_clstm ivf_clstm_t;

@@ -468,6 +468,233 @@ __global__ void clstm_weight_tables_kernel(const float* __restrict__ w, float* _
   }
 }
 
+// ---------------------------------------------------------------- hidden > 4 (up to 32, multiple of 4)
+// The reference's default is nb_lstm_units = 32 (CLSTM_4.py:9); its KTH configs use 4, which is what the
+// kernels above are shaped for (all 16 gate channels of a pixel in one thread).  Wider cells run the same
+// arithmetic blocked by 16 gate channels: the gate index stays the global g*hid + j everywhere in memory;
+// a thread handles one pixel and one block (blockIdx.y):
+//   x-conv forward: gate block gb = gates [16 gb, 16 gb + 16);
+//   cell steps: channel group q = hidden channels [4q, 4q+4) with their four gates (local o = g*4 + jj);
+//   backward convs: 4 output channels, looping over all G gates.
+// Weight tables (clstm_weight_tables_wide_kernel): wxW [gb][cin][k][k][16], whW [q][hid][k][k][16],
+// whBW [q][k][k][G][4], wxBW [cb][k][k][G][4] -- wave-uniform indices, scalar loads, as above.
+__global__ __launch_bounds__(256) void clstm_xconv_fwd_wide_kernel(
+    const float* __restrict__ x, const float* __restrict__ wxW, const float* __restrict__ bias,
+    float* __restrict__ gx, int B, int T, int Cin, int H, int W, long sB, long sC, long sT, int hid, int k,
+    int stride, int Ho, int Wo) {
+  const int G = 4 * hid;
+  const int gb = blockIdx.y;
+  const int pad = (k - 1) / 2;
+  const float* wT = wxW + (size_t)gb * Cin * k * k * 16;
+  const long total = (long)B * T * Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xo = i % Wo;
+    int yo = (i / Wo) % Ho;
+    int t = (i / ((long)Wo * Ho)) % T;
+    int b = i / ((long)Wo * Ho * T);
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = bias ? bias[gb * 16 + o] : 0.f;
+    for (int c = 0; c < Cin; ++c) {
+      const float* xp = x + b * sB + c * sC + t * sT;
+      for (int ky = 0; ky < k; ++ky) {
+        int y = yo * stride - pad + ky;
+        for (int kx = 0; kx < k; ++kx) {
+          int xx = xo * stride - pad + kx;
+          float v = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? xp[(long)y * W + xx] : 0.f;
+          const float* wp = wT + ((c * k + ky) * k + kx) * 16;
+#pragma unroll
+          for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(wp[o], v, acc[o]);
+        }
+      }
+    }
+    float* gp = gx + (((long)b * T + t) * G + gb * 16) * Ho * Wo + (long)yo * Wo + xo;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) gp[(long)o * Ho * Wo] = acc[o];
+  }
+}
+
+__global__ __launch_bounds__(256) void clstm_step_fwd_wide_kernel(
+    const float* __restrict__ gx, const float* __restrict__ whW, float* __restrict__ S, float* __restrict__ Hs,
+    int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  const int G = 4 * hid;
+  const int q = blockIdx.y;
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  const float* whT = whW + (size_t)q * hid * k * k * 16;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xo = i % Wo;
+    int yo = (i / Wo) % Ho;
+    int b = i / plane;
+    const float* gp = gx + (((long)b * T + t) * G) * plane + (long)yo * Wo + xo;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = gp[(long)((o >> 2) * hid + 4 * q + (o & 3)) * plane];
+    if (t > 0) {
+      const float* hp = Hs + (((long)b * T + (t - 1)) * hid) * plane;
+      for (int c = 0; c < hid; ++c)
+        for (int ky = 0; ky < k; ++ky) {
+          int y = yo - pad + ky;
+          for (int kx = 0; kx < k; ++kx) {
+            int xx = xo - pad + kx;
+            float v = ((unsigned)y < (unsigned)Ho && (unsigned)xx < (unsigned)Wo)
+                          ? hp[(long)c * plane + (long)y * Wo + xx] : 0.f;
+            const float* wp = whT + ((c * k + ky) * k + kx) * 16;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(wp[o], v, acc[o]);
+          }
+        }
+    }
+    float* sp = S + (((long)b * T + t) * 5 * hid) * plane + (long)yo * Wo + xo;
+    const float* cprev = (t > 0) ? S + ((((long)b * T + (t - 1)) * 5 + 4) * hid) * plane + (long)yo * Wo + xo : nullptr;
+    float* hp2 = Hs + (((long)b * T + t) * hid) * plane + (long)yo * Wo + xo;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * q + jj;
+      float ci = sigmoidf_(acc[jj]);
+      float cf = sigmoidf_(acc[4 + jj]);
+      float cg = tanhf(acc[8 + jj]);
+      float co = sigmoidf_(acc[12 + jj]);
+      float cp = cprev ? cprev[(long)j * plane] : 0.f;
+      float cc = cf * cp + ci * cg;
+      float ch = co * tanhf(cc);
+      sp[(long)(0 * hid + j) * plane] = ci;
+      sp[(long)(1 * hid + j) * plane] = cf;
+      sp[(long)(2 * hid + j) * plane] = cg;
+      sp[(long)(3 * hid + j) * plane] = co;
+      sp[(long)(4 * hid + j) * plane] = cc;
+      hp2[(long)j * plane] = ch;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void clstm_step_bwd_wide_kernel(
+    const float* __restrict__ dHpool, const float* __restrict__ whBW, const float* __restrict__ S,
+    float* __restrict__ dG, float* __restrict__ dC, int B, int T, int t, int hid, int k, int Ho, int Wo) {
+  const int G = 4 * hid;
+  const int q = blockIdx.y;
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * plane;
+  const float* whB = whBW + (size_t)q * k * k * G * 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int x = i % Wo;
+    int y = (i / Wo) % Ho;
+    int b = i / plane;
+    float dh[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dh[jj] = dHpool[(((long)b * T + t) * hid + 4 * q + jj) * plane + (long)y * Wo + x];
+    if (t + 1 < T) {
+      const float* gp = dG + (((long)b * T + (t + 1)) * G) * plane;
+      for (int ky = 0; ky < k; ++ky) {
+        int yy = y - ky + pad;
+        if ((unsigned)yy >= (unsigned)Ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int xx = x - kx + pad;
+          if ((unsigned)xx >= (unsigned)Wo) continue;
+          const float* wp = whB + (size_t)(ky * k + kx) * G * 4;
+          for (int o = 0; o < G; ++o) {
+            float g = gp[(long)o * plane + (long)yy * Wo + xx];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) dh[jj] = __builtin_fmaf(wp[o * 4 + jj], g, dh[jj]);
+          }
+        }
+      }
+    }
+    const float* sp = S + (((long)b * T + t) * 5 * hid) * plane + (long)y * Wo + x;
+    const float* cprev = (t > 0) ? S + ((((long)b * T + (t - 1)) * 5 + 4) * hid) * plane + (long)y * Wo + x : nullptr;
+    float* gout = dG + (((long)b * T + t) * G) * plane + (long)y * Wo + x;
+    float* dcp = dC + ((long)b * hid) * plane + (long)y * Wo + x;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * q + jj;
+      float ci = sp[(long)(0 * hid + j) * plane], cf = sp[(long)(1 * hid + j) * plane];
+      float cg = sp[(long)(2 * hid + j) * plane], co = sp[(long)(3 * hid + j) * plane];
+      float cc = sp[(long)(4 * hid + j) * plane];
+      float cp = cprev ? cprev[(long)j * plane] : 0.f;
+      float th = tanhf(cc);
+      float dco = dh[jj] * th;
+      float dcc = dh[jj] * co * (1.f - th * th) + ((t + 1 < T) ? dcp[(long)j * plane] : 0.f);
+      gout[(long)(0 * hid + j) * plane] = dcc * cg * (ci * (1.f - ci));
+      gout[(long)(1 * hid + j) * plane] = dcc * cp * (cf * (1.f - cf));
+      gout[(long)(2 * hid + j) * plane] = dcc * ci * (1.f - cg * cg);
+      gout[(long)(3 * hid + j) * plane] = dco * (co * (1.f - co));
+      dcp[(long)j * plane] = dcc * cf;
+    }
+  }
+}
+
+// NOTE on step order: the gate derivatives of step t for group q are written while other groups' launches
+// of the SAME step may still read dG[t+1] (never dG[t]) -- the groups of one launch are independent.
+__global__ __launch_bounds__(256) void clstm_xconv_bwd_wide_kernel(
+    const float* __restrict__ dG, const float* __restrict__ wxBW, float* __restrict__ dx, int B, int T, int Cin,
+    int H, int W, long sB, long sC, long sT, int hid, int k, int stride, int Ho, int Wo) {
+  const int G = 4 * hid;
+  const int cb = blockIdx.y;
+  const int pad = (k - 1) / 2;
+  const long plane = (long)Ho * Wo;
+  const long total = (long)B * T * H * W;
+  const float* wB = wxBW + (size_t)cb * k * k * G * 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int x = i % W;
+    int y = (i / W) % H;
+    int t = (i / ((long)W * H)) % T;
+    int b = i / ((long)W * H * T);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* gp = dG + (((long)b * T + t) * G) * plane;
+    for (int ky = 0; ky < k; ++ky) {
+      int ny = y + pad - ky;
+      if (ny < 0 || ny % stride) continue;
+      int yo = ny / stride;
+      if (yo >= Ho) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        int nx = x + pad - kx;
+        if (nx < 0 || nx % stride) continue;
+        int xo = nx / stride;
+        if (xo >= Wo) continue;
+        const float* wp = wB + (size_t)(ky * k + kx) * G * 4;
+        for (int o = 0; o < G; ++o) {
+          float g = gp[(long)o * plane + (long)yo * Wo + xo];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_fmaf(wp[o * 4 + c], g, acc[c]);
+        }
+      }
+    }
+    for (int c = 0; c < 4; ++c)
+      if (4 * cb + c < Cin) dx[b * sB + (4 * cb + c) * sC + t * sT + (long)y * W + x] = acc[c];
+  }
+}
+
+// raw [G][cin][k][k] -> wide tables.  mode 0: forward gate blocks  wF[gb][cin][k][k][16]  (o = gb*16 + oo)
+//                                     mode 1: forward channel groups wF[q][cin][k][k][16] (o = (oo>>2)*hid + 4q + (oo&3))
+//                                     backward (both): wBk[cb][k][k][G][4] = w[o][4cb + cc][ky][kx]
+__global__ void clstm_weight_tables_wide_kernel(const float* __restrict__ w, float* __restrict__ wF,
+                                                float* __restrict__ wBk, int hid, int cin, int k, int mode) {
+  const int G = 4 * hid;
+  const int nblk = G / 16;                       // gate blocks == channel groups (hid / 4)
+  const int ncb = (cin + 3) / 4;
+  const long nF = (long)nblk * cin * k * k * 16, nB = (long)ncb * k * k * G * 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nF + nB; i += (long)gridDim.x * blockDim.x) {
+    if (i < nF) {
+      int oo = i & 15;
+      long r = i >> 4;
+      int kx = r % k, ky = (r / k) % k, c = (r / (k * k)) % cin, blk = r / ((long)k * k * cin);
+      int o = mode == 0 ? blk * 16 + oo : (oo >> 2) * hid + 4 * blk + (oo & 3);
+      wF[i] = w[(((long)o * cin + c) * k + ky) * k + kx];
+    } else {
+      long qi = i - nF;
+      int cc = qi & 3;
+      long r = qi >> 2;
+      int o = r % G;
+      r /= G;
+      int kx = r % k, ky = (r / k) % k, cb = r / ((long)k * k);
+      int c = 4 * cb + cc;
+      wBk[qi] = c < cin ? w[(((long)o * cin + c) * k + ky) * k + kx] : 0.f;
+    }
+  }
+}
+
 __global__ void clstm_fill_kernel(float* p, long n, float v) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -481,6 +708,7 @@ struct LayerPlan {
   int cin, Hin, Win, Ho, Wo, Hp, Wp;
   size_t wx_off, bx_off, wh_off;                    // floats in weights arena (raw reference layout)
   size_t wxT_off, wxB_off, whT_off, whB_off;        // transposed tables for the scalar-load kernels
+  size_t wxW_off = 0, wxBW_off = 0, whW_off = 0, whBW_off = 0;   // blocked tables (hidden > 4)
   size_t gx_off, S_off, H_off, X_off, dG_off, dHp_off, dC_off, dX_off;  // floats in workspace
   size_t arg_off;                                   // bytes
 };
@@ -493,7 +721,8 @@ struct ivf_clstm {
   ivf_clstm_config cfg;
   std::vector<LayerPlan> L;
   size_t bn_scale_off, bn_shift_off, fcw_off, fcb_off, weights_floats;
-  int feat;
+  int feat;      // hid * Hp * Wp of the top layer
+  int fc_in;     // endFC inputs: feat * number of output steps
   size_t ws_bytes;
   size_t off_p, off_dp, off_flat, off_dflat, off_logits, off_probs, off_score, off_sig, off_terms, off_dreg,
       off_dsig, off_fbwd, off_pair;
@@ -510,13 +739,22 @@ extern "C" int ivf_clstm_create(const ivf_clstm_config* c, ivf_clstm_t** out) {
   IVF_CHECK_ARG(c && out, "clstm_create: null pointer");
   IVF_CHECK_ARG(c->B > 0 && c->C > 0 && c->C <= 4 && c->T > 0 && c->T <= 64 && c->H > 0 && c->W > 0,
                 "clstm_create: bad clip geometry (C<=4, T<=64)");
-  IVF_CHECK_ARG(c->hidden > 0 && c->hidden <= 4 && c->layers > 0 && c->layers <= 8,
-                "clstm_create: hidden must be 1..4 (reference configs use 4), layers 1..8");
+  IVF_CHECK_ARG(c->hidden > 0 && (c->hidden <= 4 || (c->hidden <= 32 && c->hidden % 4 == 0)) && c->layers > 0 &&
+                    c->layers <= 8,
+                "clstm_create: hidden must be 1..4 or a multiple of 4 up to 32 (CLSTM_4.py:9 default), layers 1..8");
   IVF_CHECK_ARG(c->kernel >= 1 && c->kernel <= MAXK && (c->kernel & 1) && c->stride >= 1 && c->num_classes > 0,
                 "clstm_create: kernel must be odd <= %d", MAXK);
   IVF_CHECK_ARG(c->out_step >= 0 && c->out_step < c->T, "clstm_create: out_step outside [0,T)");
+  IVF_CHECK_ARG(c->n_out_steps >= 0 && c->n_out_steps <= 16, "clstm_create: at most 16 output steps");
+  for (int e = 0; e < c->n_out_steps; ++e)
+    IVF_CHECK_ARG(c->out_steps[e] >= 0 && c->out_steps[e] < c->T && (e == 0 || c->out_steps[e] > c->out_steps[e - 1]),
+                  "clstm_create: out_steps must be increasing steps inside [0,T)");
   ivf_clstm* n = new ivf_clstm();
   n->cfg = *c;
+  if (c->n_out_steps == 0) {          // single step: the general code below sees a list of one
+    n->cfg.n_out_steps = 1;
+    n->cfg.out_steps[0] = c->out_step;
+  }
   const int hid = c->hidden, k = c->kernel, G = 4 * hid;
   size_t w = 0;
   auto takew = [&](size_t e) { size_t o = w; w += (e + 63) / 64 * 64; return o; };
@@ -544,6 +782,12 @@ extern "C" int ivf_clstm_create(const ivf_clstm_config* c, ivf_clstm_t** out) {
     p.wxB_off = takew((size_t)k * k * 64);
     p.whT_off = takew((size_t)hid * k * k * 16);
     p.whB_off = takew((size_t)k * k * 64);
+    if (hid > 4) {     // blocked tables of the wide path
+      p.wxW_off = takew((size_t)(G / 16) * cin * k * k * 16);
+      p.wxBW_off = takew((size_t)((cin + 3) / 4) * k * k * G * 4);
+      p.whW_off = takew((size_t)(hid / 4) * hid * k * k * 16);
+      p.whBW_off = takew((size_t)(hid / 4) * k * k * G * 4);
+    }
     size_t plane = (size_t)p.Ho * p.Wo;
     p.gx_off = takef(B * T * G * plane);
     p.S_off = takef(B * T * 5 * hid * plane);
@@ -557,16 +801,17 @@ extern "C" int ivf_clstm_create(const ivf_clstm_config* c, ivf_clstm_t** out) {
     cin = hid; H = p.Hp; W = p.Wp;
   }
   n->feat = hid * H * W;
+  n->fc_in = n->feat * n->cfg.n_out_steps;
   n->bn_scale_off = takew(hid);
   n->bn_shift_off = takew(hid);
-  n->fcw_off = takew((size_t)c->num_classes * n->feat);
+  n->fcw_off = takew((size_t)c->num_classes * n->fc_in);
   n->fcb_off = takew(c->num_classes);
   n->weights_floats = w;
   size_t clip = (size_t)c->C * c->T * c->H * c->W;
   n->off_p = takef(B * clip) * 4;
   n->off_dp = takef(B * clip) * 4;
-  n->off_flat = takef(B * n->feat) * 4;
-  n->off_dflat = takef(B * n->feat) * 4;
+  n->off_flat = takef(B * n->fc_in) * 4;
+  n->off_dflat = takef(B * n->fc_in) * 4;
   size_t bytes = fl * 4;
   auto takeb = [&](size_t nb) { size_t o = bytes; bytes += align_up(nb, 256); return o; };
   for (auto& p : n->L) p.arg_off = takeb(B * T * hid * p.Hp * p.Wp);
@@ -619,12 +864,21 @@ extern "C" int ivf_clstm_load_cell(ivf_clstm_t* n, int layer, const float* wxi, 
     IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.bx_off + g * hid, bx[g], (size_t)hid * 4, hipMemcpyDeviceToDevice, s));
     IVF_CHECK_HIP(hipMemcpyAsync(n->wa + p.wh_off + g * eh, wh[g], eh * 4, hipMemcpyDeviceToDevice, s));
   }
-  hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wx_off, n->wa + p.wxT_off,
-                     n->wa + p.wxB_off, 4 * hid, p.cin, k);
-  IVF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wh_off, n->wa + p.whT_off,
-                     n->wa + p.whB_off, 4 * hid, hid, k);
-  IVF_CHECK_LAUNCH();
+  if (hid > 4) {
+    hipLaunchKernelGGL(clstm_weight_tables_wide_kernel, dim3(64), dim3(256), 0, s, n->wa + p.wx_off, n->wa + p.wxW_off,
+                       n->wa + p.wxBW_off, hid, p.cin, k, 0);
+    IVF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clstm_weight_tables_wide_kernel, dim3(64), dim3(256), 0, s, n->wa + p.wh_off, n->wa + p.whW_off,
+                       n->wa + p.whBW_off, hid, hid, k, 1);
+    IVF_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wx_off, n->wa + p.wxT_off,
+                       n->wa + p.wxB_off, 4 * hid, p.cin, k);
+    IVF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clstm_weight_tables_kernel, dim3(8), dim3(256), 0, s, n->wa + p.wh_off, n->wa + p.whT_off,
+                       n->wa + p.whB_off, 4 * hid, hid, k);
+    IVF_CHECK_LAUNCH();
+  }
   n->cell_loaded[layer] = true;
   return IVF_OK;
 }
@@ -640,7 +894,7 @@ extern "C" int ivf_clstm_load_head(ivf_clstm_t* n, const float* bn_gamma, const 
     IVF_PROPAGATE(ivf_bn_fold(bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, n->wa + n->bn_scale_off,
                               n->wa + n->bn_shift_off, n->cfg.hidden, s));
   }
-  IVF_CHECK_HIP(hipMemcpyAsync(n->wa + n->fcw_off, fc_w, (size_t)n->cfg.num_classes * n->feat * 4,
+  IVF_CHECK_HIP(hipMemcpyAsync(n->wa + n->fcw_off, fc_w, (size_t)n->cfg.num_classes * n->fc_in * 4,
                                hipMemcpyDeviceToDevice, s));
   IVF_CHECK_HIP(hipMemcpyAsync(n->wa + n->fcb_off, fc_b, (size_t)n->cfg.num_classes * 4, hipMemcpyDeviceToDevice, s));
   n->head_loaded = true;
@@ -675,11 +929,23 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
       in = n->wsf(q.X_off);
       sC = (long)q.Hp * q.Wp; sT = sC * hid; sB = sT * T;
     }
-    hipLaunchKernelGGL(clstm_xconv_fwd_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo, 256, 16384)), dim3(256), 0, s, in,
-                       n->wa + p.wxT_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
-                       hid, k, c.stride, p.Ho, p.Wo);
+    if (hid > 4)
+      hipLaunchKernelGGL(clstm_xconv_fwd_wide_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo, 256, 16384), hid / 4),
+                         dim3(256), 0, s, in, n->wa + p.wxW_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin,
+                         p.Win, sB, sC, sT, hid, k, c.stride, p.Ho, p.Wo);
+    else
+      hipLaunchKernelGGL(clstm_xconv_fwd_kernel, dim3(grid_for((long)b * T * p.Ho * p.Wo, 256, 16384)), dim3(256), 0, s, in,
+                         n->wa + p.wxT_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
+                         hid, k, c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
     for (int t = 0; t < T; ++t) {
+      if (hid > 4) {
+        hipLaunchKernelGGL(clstm_step_fwd_wide_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384), hid / 4),
+                           dim3(256), 0, s, n->wsf(p.gx_off), n->wa + p.whW_off, n->wsf(p.S_off), n->wsf(p.H_off), b, T,
+                           t, hid, k, p.Ho, p.Wo);
+        IVF_CHECK_LAUNCH();
+        continue;
+      }
       static const int split_below = getenv("IVF_CLSTM_SPLIT") ? atoi(getenv("IVF_CLSTM_SPLIT")) : (1 << 30);
       if (hid <= 4 && (long)b * p.Ho * p.Wo <= split_below)
         hipLaunchKernelGGL(clstm_step_fwd_split_kernel, dim3((unsigned)(((long)b * p.Ho * p.Wo + 63) / 64)), dim3(256), 0,
@@ -696,14 +962,17 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
                        p.Ho, p.Wo, p.Hp, p.Wp);
     IVF_CHECK_LAUNCH();
   }
-  // CLSTM_4.py:78-80: endFC on output[-1] (last effective step) flattened [hid*Hp*Wp]
+  // CLSTM_4.py:73-80: endFC on output[-1] (last effective step) flattened [hid*Hp*Wp], or on the
+  // effective steps' outputs concatenated in step order (use_entire_seq)
   const LayerPlan& q = n->L.back();
   float* flat = n->at<float>(n->off_flat);
-  IVF_CHECK_HIP(hipMemcpy2DAsync(flat, (size_t)n->feat * 4, n->wsf(q.X_off) + (size_t)c.out_step * n->feat,
-                                 (size_t)T * n->feat * 4, (size_t)n->feat * 4, b, hipMemcpyDeviceToDevice, s));
+  for (int e = 0; e < c.n_out_steps; ++e)
+    IVF_CHECK_HIP(hipMemcpy2DAsync(flat + (size_t)e * n->feat, (size_t)n->fc_in * 4,
+                                   n->wsf(q.X_off) + (size_t)c.out_steps[e] * n->feat, (size_t)T * n->feat * 4,
+                                   (size_t)n->feat * 4, b, hipMemcpyDeviceToDevice, s));
   float* lg = n->at<float>(n->off_logits);
   float* pr = n->at<float>(n->off_probs);
-  IVF_PROPAGATE(ivf_head_fwd(flat, n->wa + n->fcw_off, n->wa + n->fcb_off, nullptr, lg, pr, b, 1, n->feat,
+  IVF_PROPAGATE(ivf_head_fwd(flat, n->wa + n->fcw_off, n->wa + n->fcb_off, nullptr, lg, pr, b, 1, n->fc_in,
                              c.num_classes, c.softmax, s));
   size_t nb = (size_t)b * c.num_classes * 4;
   if (logits) IVF_CHECK_HIP(hipMemcpyAsync(logits, lg, nb, hipMemcpyDeviceToDevice, s));
@@ -720,14 +989,16 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
   float* flat = n->at<float>(n->off_flat);
   float* dflat = n->at<float>(n->off_dflat);
   IVF_PROPAGATE(ivf_head_bwd(flat, n->wa + n->fcw_off, n->at<float>(n->off_probs), target, dout, score, nullptr,
-                             dflat, b, 1, n->feat, c.num_classes, c.softmax, 0, s));
-  // gradient of the pooled top-layer outputs: zero except at out_step
+                             dflat, b, 1, n->fc_in, c.num_classes, c.softmax, 0, s));
+  // gradient of the pooled top-layer outputs: zero except at the output step(s)
   const LayerPlan& top = n->L.back();
   long ntop = (long)b * T * n->feat;
   hipLaunchKernelGGL(clstm_fill_kernel, dim3(grid_for(ntop)), dim3(256), 0, s, n->wsf(top.dX_off), ntop, 0.f);
   IVF_CHECK_LAUNCH();
-  IVF_CHECK_HIP(hipMemcpy2DAsync(n->wsf(top.dX_off) + (size_t)c.out_step * n->feat, (size_t)T * n->feat * 4, dflat,
-                                 (size_t)n->feat * 4, (size_t)n->feat * 4, b, hipMemcpyDeviceToDevice, s));
+  for (int e = 0; e < c.n_out_steps; ++e)
+    IVF_CHECK_HIP(hipMemcpy2DAsync(n->wsf(top.dX_off) + (size_t)c.out_steps[e] * n->feat, (size_t)T * n->feat * 4,
+                                   dflat + (size_t)e * n->feat, (size_t)n->fc_in * 4, (size_t)n->feat * 4, b,
+                                   hipMemcpyDeviceToDevice, s));
   for (int i = (int)n->L.size() - 1; i >= 0; --i) {
     const LayerPlan& p = n->L[i];
     hipLaunchKernelGGL(clstm_unpool_bwd_kernel, dim3(grid_for((long)b * T * hid * p.Ho * p.Wo)), dim3(256), 0, s,
@@ -736,6 +1007,13 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
     IVF_CHECK_LAUNCH();
     for (int t = T - 1; t >= 0; --t) {
       static const int split_below = getenv("IVF_CLSTM_SPLIT") ? atoi(getenv("IVF_CLSTM_SPLIT")) : (1 << 30);
+      if (hid > 4) {
+        hipLaunchKernelGGL(clstm_step_bwd_wide_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384), hid / 4),
+                           dim3(256), 0, s, n->wsf(p.dHp_off), n->wa + p.whBW_off, n->wsf(p.S_off), n->wsf(p.dG_off),
+                           n->wsf(p.dC_off), b, T, t, hid, k, p.Ho, p.Wo);
+        IVF_CHECK_LAUNCH();
+        continue;
+      }
       if (hid <= 4 && (long)b * p.Ho * p.Wo <= split_below)
         hipLaunchKernelGGL(clstm_step_bwd_split_kernel, dim3((unsigned)(((long)b * p.Ho * p.Wo + 63) / 64)), dim3(256), 0,
                            s, n->wsf(p.dHp_off), n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off),
@@ -771,6 +1049,11 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
       }
 #undef IVF_XB
     }
+    else if (hid > 4)
+      hipLaunchKernelGGL(clstm_xconv_bwd_wide_kernel,
+                         dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384), (p.cin + 3) / 4), dim3(256), 0, s,
+                         n->wsf(p.dG_off), n->wa + p.wxBW_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,
+                         c.stride, p.Ho, p.Wo);
     else
       hipLaunchKernelGGL(clstm_xconv_bwd_kernel, dim3(grid_for((long)b * T * p.Hin * p.Win, 256, 16384)), dim3(256), 0,
                          s, n->wsf(p.dG_off), n->wa + p.wxB_off, out, b, T, p.cin, p.Hin, p.Win, sB, sC, sT, hid, k,

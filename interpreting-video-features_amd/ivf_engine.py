@@ -255,7 +255,7 @@ class CLSTMEngine:
     convolution_lstm.py:96-132) on `max_batch` clips [C,T,H,W]."""
 
     def __init__(self, num_classes, clip_shape, max_batch=1, hidden=4, layers=2, kernel=5, stride=2,
-                 softmax=False, batch_norm=True, out_step=None, device=None):
+                 softmax=False, batch_norm=True, out_step=None, out_steps=None, device=None):
         L.require_gpu()
         self.device = torch.device(device if device is not None else "cuda")
         C, T, H, W = clip_shape
@@ -266,6 +266,13 @@ class CLSTMEngine:
         cfg.softmax = 1 if softmax else 0
         cfg.batch_norm = 1 if batch_norm else 0
         cfg.out_step = T - 1 if out_step is None else int(out_step)
+        if out_steps is not None:           # use_entire_seq: every effective step reached feeds endFC
+            if not 1 <= len(out_steps) <= 16:
+                raise L.IvfError("between 1 and 16 output steps")
+            cfg.n_out_steps = len(out_steps)
+            for i, sv in enumerate(out_steps):
+                cfg.out_steps[i] = int(sv)
+            cfg.out_step = int(out_steps[-1])
         self.cfg = cfg
         self.clip_shape = (C, T, H, W)
         self.max_batch = int(max_batch)

@@ -50,7 +50,7 @@ class I3DConfig(Structure):
 class CLSTMConfig(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "C", "T", "H", "W", "hidden", "layers", "kernel", "stride", "num_classes",
-        "softmax", "batch_norm", "out_step")]
+        "softmax", "batch_norm", "out_step", "n_out_steps")] + [("out_steps", c_int * 16)]
 
 
 _P = c_void_p

@@ -76,7 +76,7 @@ def i3d_state_dict(num_classes=174, in_channels=3, stride_mod_layers="",
 
 def clstm_state_dict(num_classes=6, hidden=4, channels=1, kernel=5, layers=2,
                      image_size=(160, 120), conv_stride=2, pool=2, tag="clstm",
-                     fc_gain=4.0):
+                     fc_gain=4.0, fc_mult=1):
     """Reference key scheme of models/CLSTM_4.py + convolution_lstm.py:22-29, 85."""
     sd = {}
     sd["clstm.bn.weight"] = uniform(f"{tag}/bn.weight", (hidden,), 0.8, 1.2)
@@ -96,7 +96,7 @@ def clstm_state_dict(num_classes=6, hidden=4, channels=1, kernel=5, layers=2,
                 f"{tag}/cell{i}.Wh{g}.weight", (hidden, hidden, kernel, kernel), -bh, bh)
         cin = hidden
     red = (conv_stride * pool) ** layers
-    feat = hidden * int(image_size[0] / red) * int(image_size[1] / red)
+    feat = fc_mult * hidden * int(image_size[0] / red) * int(image_size[1] / red)   # fc_mult: use_entire_seq
     bf = float(fc_gain / np.sqrt(feat))
     sd["endFC.weight"] = uniform(f"{tag}/endFC.weight", (num_classes, feat), -bf, bf)
     sd["endFC.bias"] = uniform(f"{tag}/endFC.bias", (num_classes,), -0.1, 0.1)

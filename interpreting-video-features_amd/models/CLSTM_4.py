@@ -76,6 +76,18 @@ class Model(torch.nn.Module):
             raise IndexError("list index out of range")
         return max(reached)
 
+    def _out_steps(self):
+        """use_entire_seq (CLSTM_4.py:73-76): the outputs of every effective step reached, in step order.
+        The reference's `torch.stack(output).view(-1, E*feat)` equals this per-clip concatenation for one
+        clip; for B > 1 its view mixes the clips of a batch (rows are cut from the [E,B,feat] stack), here
+        every row stays the clip's own concatenation, which is what one-clip calls of the reference give."""
+        reached = sorted({s for s in self.effective_step if 0 <= s < self.step})
+        if len(reached) != len(self.effective_step):
+            raise RuntimeError("shape '[-1, %d]' is invalid: %d of the %d effective steps lie inside the %d-step clip"
+                               % (len(self.effective_step) * self._feat(), len(reached), len(self.effective_step),
+                                  self.step))
+        return reached
+
     def refresh(self):
         self._weights_version += 1
 
@@ -96,10 +108,8 @@ class Model(torch.nn.Module):
         L.require_gpu(x)
         if self.training:
             raise L.IvfError("the HIP path implements eval-mode semantics; call model.eval() first")
-        if self.use_entire_seq:
-            raise L.IvfError("use_entire_seq=True is not built (the reference drivers use False)")
-        if self.nb_lstm_units > 4:
-            raise L.IvfError("the HIP ConvLSTM plan is built for nb_lstm_units <= 4 (config_clstm_kth.py:40)")
+        if self.nb_lstm_units > 4 and (self.nb_lstm_units > 32 or self.nb_lstm_units % 4):
+            raise L.IvfError("the HIP ConvLSTM plan takes nb_lstm_units 1..4 or a multiple of 4 up to 32")
         key = tuple(x.shape[1:])
         if key[1] != self.step:
             raise L.IvfError(f"clip has {key[1]} frames, model was built with step={self.step}")
@@ -110,7 +120,9 @@ class Model(torch.nn.Module):
                                          layers=self.lstm_layers, kernel=self.c_kernel_size[0],
                                          stride=self.conv_stride, softmax=bool(self.add_softmax),
                                          batch_norm=bool(self.batch_normalization),
-                                         out_step=self._out_step(), device=x.device)
+                                         out_step=self._out_step(),
+                                         out_steps=self._out_steps() if self.use_entire_seq else None,
+                                         device=x.device)
             ent = [-1, eng]
             self._engine_cache[key] = ent
         if ent[0] != self._weights_version:

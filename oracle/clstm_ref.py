@@ -45,10 +45,14 @@ def convlstm(x, sd, layers, hidden, kernel, stride, steps, effective_step, batch
 
 
 def forward(x, sd, layers=2, hidden=4, kernel=5, stride=2, steps=32,
-            effective_step=(7, 15, 23, 31), add_softmax=False, batch_norm=True):
-    """CLSTM_4.py:69-85 with use_entire_seq=False: endFC on the flattened LAST
-    effective-step output."""
+            effective_step=(7, 15, 23, 31), add_softmax=False, batch_norm=True, use_entire_seq=False):
+    """CLSTM_4.py:69-85: endFC on the flattened LAST effective-step output, or (use_entire_seq,
+    :73-76) on `torch.stack(output).view(-1, E*feat)` -- restated literally, so for B > 1 it mixes the
+    clips of a batch exactly as the reference does; call it with one clip for per-clip semantics."""
     outs = convlstm(x, sd, layers, hidden, kernel, stride, steps, effective_step, batch_norm)
-    flat = outs[-1].reshape(x.shape[0], -1)
+    if use_entire_seq:
+        flat = torch.stack(outs).reshape(-1, len(outs) * outs[0][0].numel())
+    else:
+        flat = outs[-1].reshape(x.shape[0], -1)
     y = F.linear(flat, sd['endFC.weight'], sd['endFC.bias'])
     return torch.softmax(y, dim=1) if add_softmax else y

@@ -561,6 +561,31 @@ def gen_viz():
     save('viz', **out)
 
 
+def gen_clstm_seq():
+    """CLSTM_4.Model(use_entire_seq=True) (CLSTM_4.py:73-76): endFC over the four effective steps'
+    outputs; one clip per call (the reference's view mixes the clips of a larger batch)."""
+    out = {}
+    m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=3, conv_kernel_size=(5, 5), lstm_layers=2, step=32,
+                      image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31], use_entire_seq=True,
+                      add_softmax=True).eval()
+    m.load_state_dict(R.to_torch(R.clstm_state_dict(channels=3, tag='clstm_seq', fc_mult=4)))
+    for cid in (3, 4):
+        x = torch.from_numpy(R.clip(cid, 3, 32, 120, 160) / 255.0)[None].float().requires_grad_()
+        y = m(x)
+        m.add_softmax = False
+        with torch.no_grad():
+            out[f'clip{cid}_logits'] = m(x).numpy()
+        m.add_softmax = True
+        y[0, 2].backward()
+        out[f'clip{cid}_probs'] = y.detach().numpy()
+        dx = x.grad.numpy().ravel()
+        di = sample_idx(f'g/clstm_seq/{cid}/dx', dx.size, 4096)
+        out[f'clip{cid}_dx_idx'] = di
+        out[f'clip{cid}_dx_val'] = dx[di]
+        out[f'clip{cid}_dx_sum_per_frame'] = x.grad.numpy().astype(np.float64).sum(axis=(1, 3, 4))
+    save('clstm_seq', **out)
+
+
 def gen_ingest():
     """Clip ingest: the reference loader classes on small synthetic JPEG
     folders.  The fixture holds the JPEG bytes themselves (a few KB) and the loader output."""
@@ -608,7 +633,7 @@ def gen_ingest():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest',
-                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz']
+                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz', 'clstm_seq']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

@@ -84,10 +84,12 @@ def test_clstm_dropin_model(golden):
 
 
 @pytest.mark.parametrize("C,T,H,W,hidden,kernel,stride", [(2, 6, 24, 32, 3, 3, 2), (1, 5, 16, 24, 4, 5, 1),
-                                                          (3, 4, 18, 26, 2, 3, 1)])
+                                                          (3, 4, 18, 26, 2, 3, 1), (3, 5, 24, 32, 8, 5, 2),
+                                                          (1, 4, 16, 16, 32, 3, 2), (2, 3, 12, 20, 16, 3, 1)])
 def test_clstm_other_geometries_match_oracle(C, T, H, W, hidden, kernel, stride):
-    """Geometries off the reference's (k 5, stride 2, hidden 4): the generic x-conv backward and the
-    hidden < 4 forms of the wave-split cell steps, against the CPU oracle (forward and dL/dx)."""
+    """Geometries off the reference's (k 5, stride 2, hidden 4): the generic x-conv backward, the
+    hidden < 4 forms of the wave-split cell steps and the blocked kernels for hidden 8 / 16 / 32
+    (CLSTM_4.py:9 default nb_lstm_units=32), against the CPU oracle (forward and dL/dx)."""
     import ivf_engine
     import ivf_recipe as R
     from oracle import clstm_ref
@@ -183,3 +185,30 @@ def test_clstm_out_step_is_last_effective_step_reached():
                        image_size=(64, 48), conv_stride=2, effective_step=[4, 8], add_softmax=True).cuda().eval()
     with pytest.raises(IndexError):
         m2(torch.zeros(1, 1, 3, 48, 64).cuda())          # the reference's output[-1] on an empty list
+
+
+def test_clstm_use_entire_seq(golden):
+    """use_entire_seq=True (CLSTM_4.py:73-76) through the drop-in Model: forward and input gradient vs the
+    reference model's own output, two clips in ONE batch (each row must be that clip's own result)."""
+    import ivf_recipe as R
+    from models import CLSTM_4
+    g = golden('clstm_seq')
+    m = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=3, conv_kernel_size=(5, 5), lstm_layers=2, step=32,
+                      image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31], use_entire_seq=True,
+                      add_softmax=True)
+    m.load_state_dict(R.to_torch(R.clstm_state_dict(channels=3, tag='clstm_seq', fc_mult=4)))
+    m = m.cuda().eval()
+    x = torch.from_numpy(np.stack([R.clip(3, 3, 32, 120, 160), R.clip(4, 3, 32, 120, 160)]) / 255.0).float().cuda()
+    x.requires_grad_()
+    y = m(x)
+    assert rel_err(y[0:1].detach().cpu().numpy(), g['clip3_probs']) < 1e-3
+    assert rel_err(y[1:2].detach().cpu().numpy(), g['clip4_probs']) < 1e-3
+    (y[0, 2] + y[1, 2]).backward()
+    dx = x.grad.cpu().numpy()
+    for i, cid in enumerate((3, 4)):
+        assert rel_err(dx[i].ravel()[g[f'clip{cid}_dx_idx']], g[f'clip{cid}_dx_val']) < 2e-3
+        assert rel_err(dx[i].astype(np.float64).sum(axis=(0, 2, 3)), g[f'clip{cid}_dx_sum_per_frame'][0]) < 2e-3
+    m2 = CLSTM_4.Model(num_classes=6, nb_lstm_units=4, channels=3, conv_kernel_size=(5, 5), lstm_layers=2, step=16,
+                       image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31], use_entire_seq=True)
+    with pytest.raises(RuntimeError):          # the reference's .view fails when effective steps lie past `step`
+        m2.cuda().eval()(torch.zeros(1, 3, 16, 120, 160).cuda())

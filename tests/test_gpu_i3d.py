@@ -63,7 +63,9 @@ def _check_forward_backward(eng, tag, shape, g, clip_id=7):
     # which feeds both sides the same activations.
     dxn = dx.cpu().numpy()
     sample, ref = dxn.ravel()[g[f'{tag}_dx_idx']].astype(np.float64), g[f'{tag}_dx_val'].astype(np.float64)
-    assert np.linalg.norm(sample - ref) / np.linalg.norm(ref) < (3e-2 if eng.math == "fp32" else 5e-2)
+    l2 = np.linalg.norm(sample - ref) / np.linalg.norm(ref)
+    note(f"whole-chain dx {tag} {eng.math}: sampled L2 {l2:.2e}, max {rel_err(sample, ref):.2e}")
+    assert l2 < (3e-2 if eng.math == "fp32" else 5e-2)
     assert rel_err(sample, ref) < 8e-2
     assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))

@@ -304,3 +304,15 @@ def test_viz_blend_matches_reference(golden):
     lut = viz_ref.jet_lut_bgr()
     assert lut.shape == (256, 3) and lut.dtype == np.uint8
     assert lut[0].tolist() == [143, 0, 0] and lut[255].tolist() == [0, 0, 128] and lut[128].tolist()[1] == 255
+
+
+def test_clstm_use_entire_seq_matches_reference(golden):
+    """CLSTM_4.py:73-76: endFC over the concatenated outputs of all effective steps."""
+    g = golden('clstm_seq')
+    sd = R.to_torch(R.clstm_state_dict(channels=3, tag='clstm_seq', fc_mult=4))
+    for cid in (3, 4):
+        x = torch.from_numpy(R.clip(cid, 3, 32, 120, 160) / 255.0)[None].float().requires_grad_()
+        y = clstm_ref.forward(x, sd, add_softmax=True, use_entire_seq=True)
+        assert rel_err(y.detach().numpy(), g[f'clip{cid}_probs']) < 1e-5
+        y[0, 2].backward()
+        assert rel_err(x.grad.numpy().ravel()[g[f'clip{cid}_dx_idx']], g[f'clip{cid}_dx_val']) < 1e-4
