@@ -328,6 +328,12 @@ int ivf_i3d_perturbed_forward(ivf_i3d_t* net, const float* x, int b, const float
  * probs [b,K] optional. */
 int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int* target, int per_frame, int out_h,
                     int out_w, float* cam, float* probs, ivf_stream_t stream);
+/* The same for any single endpoint of the model as target layer (pytorch-grad-cam/grad-cam.py:23-54
+ * hooks the OUTPUT of the named module: Conv3d_1a_7x7, MaxPool3d_2a_3x3, ..., Mixed_5c): forward,
+ * backward-data from the class score down to that endpoint with ITS gradient left ungated, then the
+ * Grad-CAM reduction on [T',H',W',C'] and the resize with step = T / T'. */
+int ivf_i3d_gradcam_layer(ivf_i3d_t* net, const float* x, int b, const int* target, const char* layer,
+                          int per_frame, int out_h, int out_w, float* cam, float* probs, ivf_stream_t stream);
 /* argmax over K of probs [b,K] -> target [b] (np.argmax, grad_cam_videos.py:69-70). */
 int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream);
 

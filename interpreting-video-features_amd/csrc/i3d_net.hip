@@ -8,6 +8,7 @@
 // No autograd: only dL/d(input) is propagated, activations are kept
 // once as the ReLU gates, Inception branches write straight into their slice of the
 // concatenated output (no torch.cat copy).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,7 @@ struct ivf_i3d {
   std::vector<ConvLayer> convs;   // registration order, last = logits
   std::vector<Op> ops;
   int feat_buf = -1;
+  int cam_buf = -1;      // Grad-CAM target endpoint of the pass in flight (-1: none): its gradient stays UNGATED
   size_t weights_floats = 0;
   size_t ws_bytes = 0;
   // misc workspace offsets (bytes)
@@ -322,9 +324,15 @@ static int build_plan(ivf_i3d* n) {
   n->off_dsig = takeb(B * T * 4);
   n->off_fbwd = takeb(ivf_freeze_bwd_workspace_bytes((int)B, T));
   n->off_target = takeb(B * 4);
-  n->off_cam = takeb(B * f.T * f.H * f.W * 4);
+  size_t max_pos = 0, max_t = 0;      // Grad-CAM on any endpoint (ivf_i3d_gradcam_layer)
+  for (const auto& bf : n->bufs) {
+    if (bf.name == "input" || bf.name.find('.') != std::string::npos) continue;
+    max_pos = std::max(max_pos, (size_t)bf.T * bf.H * bf.W);
+    max_t = std::max(max_t, (size_t)bf.T);
+  }
+  n->off_cam = takeb(B * max_pos * 4);
   n->off_camw = takeb(B * 1024 * 4);
-  n->off_mm = takeb(B * f.T * 2 * 4);
+  n->off_mm = takeb(B * max_t * 2 * 4);
   n->off_dfeat_raw = takeb(B * f.per_clip() * 4);
   n->off_pair = takeb(B * T * 12);
   n->ws_bytes = bytes;
@@ -392,7 +400,9 @@ static void fill_pool(const ivf_i3d* n, const Op& o, int b, ivf_pool3d_desc* d) 
   d->pT = o.p[0]; d->pH = o.p[1]; d->pW = o.p[2];
   // a pool that owes its input gradient the ReLU gate marks dead windows in the forward
   // instead of re-reading the activation in the backward
-  d->gate_nonpos = o.bwd_mask;
+  // (not for the Grad-CAM target: the hook of grad-cam.py:50-51 sees the gradient w.r.t. the endpoint's
+  // OUTPUT, before its own ReLU gate, so the true arg-max must be kept even in dead windows)
+  d->gate_nonpos = o.bwd_mask && o.src != n->cam_buf;
 }
 
 static int check_ready(const ivf_i3d* n, int b) {
@@ -446,8 +456,9 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
                              n->cfg.num_classes, n->cfg.softmax, 1, s));
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     const Op& o = n->ops[i];
+    if (n->cam_buf >= 0 && o.dst == n->cam_buf) break;   // Grad-CAM pass: the target's gradient is complete
     if (o.bwd_skip) continue;
-    const float* gate = o.bwd_mask ? n->act(o.src) : nullptr;
+    const float* gate = (o.bwd_mask && o.src != n->cam_buf) ? n->act(o.src) : nullptr;
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
@@ -733,6 +744,36 @@ extern "C" int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int*
   IVF_CHECK_ARG(c.T / f.T >= 1, "i3d_gradcam: clip shorter than the feature map");
   return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, f.T, f.H, f.W, out_h, out_w,
                                   c.T / f.T, per_frame, s);
+}
+
+extern "C" int ivf_i3d_gradcam_layer(ivf_i3d_t* net, const float* x, int b, const int* target, const char* layer,
+                                     int per_frame, int out_h, int out_w, float* cam, float* probs,
+                                     ivf_stream_t stream) {
+  IVF_PROPAGATE(check_ready(net, b));
+  IVF_CHECK_ARG(x && target && layer && cam && out_h > 0 && out_w > 0, "i3d_gradcam_layer: bad args");
+  int X = -1;
+  for (size_t i = 1; i < net->bufs.size(); ++i)
+    if (net->bufs[i].name == layer && net->bufs[i].name.find('.') == std::string::npos) X = (int)i;
+  if (X < 0) {
+    set_error("i3d_gradcam_layer: '%s' is not an endpoint of the model (Conv3d_1a_7x7 ... Mixed_5c)", layer);
+    return IVF_ERR_BAD_ARG;
+  }
+  if (X == net->feat_buf) return ivf_i3d_gradcam(net, x, b, target, per_frame, out_h, out_w, cam, probs, stream);
+  const ivf_i3d_config& c = net->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  const ActBuf& t = net->bufs[X];
+  IVF_CHECK_ARG(c.T / t.T >= 1, "i3d_gradcam_layer: clip shorter than the endpoint's map");
+  net->cam_buf = X;
+  int rc = ivf_i3d_forward(net, x, b, nullptr, probs, s);
+  if (rc == IVF_OK) rc = run_backward(net, b, target, nullptr, nullptr, s);   // stops above X, X ungated
+  net->cam_buf = -1;
+  IVF_PROPAGATE(rc);
+  const int npos = t.T * t.H * t.W;
+  float* wts = net->at<float>(net->off_camw);
+  float* cm = net->at<float>(net->off_cam);
+  IVF_PROPAGATE(ivf_gradcam_reduce(net->act(X), net->grad(X), wts, cm, b, npos, t.C, s));
+  return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, t.T, t.H, t.W, out_h, out_w, c.T / t.T,
+                                  per_frame, s);
 }
 
 extern "C" double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net) {

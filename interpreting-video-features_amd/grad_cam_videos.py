@@ -17,6 +17,16 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") and not hasattr(model, "_engine_for") else model
 
 
+def _one_target(target_layers):
+    """Any ONE endpoint of the model may be the target layer.  With several, the reference pairs
+    `features[-1]` (the LAST target in forward order) with `gradients[-1]` (the hook that fired last in the
+    backward pass, i.e. the FIRST target): activations and gradients of different layers -- refused."""
+    if len(target_layers) != 1:
+        raise L.IvfError("GradCamVideo takes exactly one target layer (the reference mixes the activations of "
+                         "the last target with the gradients of the first when given several)")
+    return target_layers[0]
+
+
 class FeatureExtractor():
     """pytorch-grad-cam/grad-cam.py:11-54: activations of the target layers and the
     output of the last feature module.  Gradients are produced by the HIP head
@@ -35,15 +45,12 @@ class FeatureExtractor():
         if self.archType != "I3D":
             raise L.IvfError("FeatureExtractor: only archType 'I3D' is built; the reference's CLSTM branch "
                              "refers to attributes CLSTM_4.Model does not have (SURVEY.md F5)")
-        for t in self.target_layers:
-            if t != 'Mixed_5c':
-                raise L.IvfError(f"target layer '{t}': only 'Mixed_5c' (the reference drivers' choice, "
-                                 "smth:258) is exposed by the HIP plan")
+        _one_target(self.target_layers)
         self.gradients = []
         eng = self.model._engine_for(x)
         eng.forward(x)
-        feat = eng.endpoint('Mixed_5c', x.shape[0])
-        return [feat for _ in self.target_layers], feat
+        acts = [eng.endpoint(t, x.shape[0]) for t in self.target_layers]
+        return acts, eng.endpoint('Mixed_5c', x.shape[0])
 
 
 class ModelOutputs():
@@ -115,9 +122,7 @@ class GradCamVideo(GradCam):
     def __call__(self, input, index=None):
         if self.archType != "I3D":
             raise L.IvfError("GradCamVideo: only archType 'I3D' is built (SURVEY.md F5)")
-        for t in self.extractor.feature_extractor.target_layers:
-            if t != 'Mixed_5c':
-                raise L.IvfError(f"target layer '{t}': only 'Mixed_5c' is exposed by the HIP plan")
+        layer = _one_target(self.extractor.feature_extractor.target_layers)
         x = input.cuda() if self.cuda else input
         L.require_gpu(x)
         if x.shape[0] != 1:
@@ -127,6 +132,7 @@ class GradCamVideo(GradCam):
         if index is not None:
             target = [int(index)]                           # grad_cam_videos.py:69-72
         width, height = self.input_spatial_size             # cv2 dsize order, grad_cam_videos.py:119-120
-        cam, output = eng.gradcam(x, target, per_frame=bool(self.normalizePerFrame), out_hw=(height, width))
+        cam, output = eng.gradcam(x, target, per_frame=bool(self.normalizePerFrame), out_hw=(height, width),
+                                  layer=layer)
         cam_vid = cam[0].cpu().numpy().astype(np.float32)
         return cam_vid, output

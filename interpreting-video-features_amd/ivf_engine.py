@@ -229,8 +229,9 @@ class I3DEngine:
             L.check(L.lib().ivf_argmax(L.ptr(L.f32c(probs)), b, probs.shape[1], L.ptr(t), L.stream()))
         return t
 
-    def gradcam(self, x, target=None, per_frame=True, out_hw=None):
-        """GradCamVideo for b clips: (cam [b,T,H,W], probs [b,K])."""
+    def gradcam(self, x, target=None, per_frame=True, out_hw=None, layer="Mixed_5c"):
+        """GradCamVideo for b clips: (cam [b,T,H,W], probs [b,K]).  `layer`: the target endpoint
+        (Conv3d_1a_7x7 ... Mixed_5c; the reference drivers use Mixed_5c, smth:258)."""
         x = self._clip(x)
         b = x.shape[0]
         C, T, H, W = self.clip_shape
@@ -240,13 +241,15 @@ class I3DEngine:
         tgt = self._targets(target, b)
         p = c_void_p()
         Tf = c_int()
-        L.check(L.lib().ivf_i3d_endpoint(self._h, b"Mixed_5c", byref(p), byref(Tf), None, None, None, None))
+        if "." in layer or layer == "input":
+            raise L.IvfError(f"'{layer}' is not an endpoint of the model")
+        L.check(L.lib().ivf_i3d_endpoint(self._h, layer.encode(), byref(p), byref(Tf), None, None, None, None))
         frames = Tf.value * (T // Tf.value)
         cam = torch.empty(b, frames, oh, ow, device=self.device)
         probs = torch.empty(b, self.K, device=self.device)
         with torch.cuda.device(self.device):
-            L.check(L.lib().ivf_i3d_gradcam(self._h, L.ptr(x), b, L.ptr(tgt), 1 if per_frame else 0, oh, ow,
-                                            L.ptr(cam), L.ptr(probs), L.stream()))
+            L.check(L.lib().ivf_i3d_gradcam_layer(self._h, L.ptr(x), b, L.ptr(tgt), layer.encode(),
+                                                  1 if per_frame else 0, oh, ow, L.ptr(cam), L.ptr(probs), L.stream()))
         return cam, probs
 
 

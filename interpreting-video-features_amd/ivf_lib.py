@@ -106,6 +106,7 @@ _SIGS = {
     "ivf_i3d_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     "ivf_i3d_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
     "ivf_i3d_gradcam": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
+    "ivf_i3d_gradcam_layer": (c_int, [_P, _P, _I, _P, c_char_p, _I, _I, _I, _P, _P, _P]),
     "ivf_i3d_conv_flops_per_clip": (ctypes.c_double, [_P]),
     "ivf_conv3d_variants": (c_int, [POINTER(ConvDesc), POINTER(c_int), _I]),
     "ivf_i3d_num_conv_ops": (c_int, [_P]),

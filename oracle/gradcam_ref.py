@@ -68,9 +68,22 @@ def cam_from_activations(act, grad, clip_size, width, height, normalize_per_fram
 
 
 def gradcam_i3d(x, sd, index=None, pool_kernel=(2, 7, 7), softmax=True,
-                width=224, height=224, normalize_per_frame=True, **kw):
-    """GradCamVideo.__call__ for archType 'I3D', target layer Mixed_5c.
+                width=224, height=224, normalize_per_frame=True, layer='Mixed_5c', **kw):
+    """GradCamVideo.__call__ for archType 'I3D' and ONE target layer (any endpoint: the hook of
+    pytorch-grad-cam/grad-cam.py:50-51 sits on the named module's output).
     x [1,C,T,H,W].  Returns (cam_vid [T,H,W], output [1,K], extras)."""
+    if layer != 'Mixed_5c':
+        eps = {}
+        xin = x.detach().clone().requires_grad_()
+        last = i3d_ref.features(xin, sd, endpoints=eps, **kw)
+        feat = eps[layer]
+        _, out = i3d_ref.head(last, sd, pool_kernel, softmax)
+        if index is None:
+            index = int(np.argmax(out.detach().numpy()))
+        grad, = torch.autograd.grad(out[0, index], feat)
+        vid, weights, cam = cam_from_activations(
+            feat.detach().numpy()[0], grad.numpy()[0], x.shape[2], width, height, normalize_per_frame)
+        return vid, out.detach(), dict(weights=weights, cam=cam, index=index, feat=feat.detach(), grad=grad)
     feat = i3d_ref.features(x, sd, **kw).detach().requires_grad_()
     _, out = i3d_ref.head(feat, sd, pool_kernel, softmax)
     if index is None:

@@ -586,6 +586,24 @@ def gen_clstm_seq():
     save('clstm_seq', **out)
 
 
+def gen_gradcam_layers():
+    """GradCamVideo with target layers other than Mixed_5c (pytorch-grad-cam/grad-cam.py:23-54 hooks the
+    output of any named module): a conv endpoint, a pool endpoint, an Inception endpoint feeding a pool and
+    one feeding the next Inception module."""
+    out = {}
+    m = _i3d(False)
+    x = torch.from_numpy(R.clip(11))[None]
+    for layer in ('Conv3d_2c_3x3', 'MaxPool3d_3a_3x3', 'Mixed_3c', 'Mixed_4c', 'Mixed_4f', 'Mixed_5b'):
+        gc = ref_gc.GradCamVideo(model=m, target_layer_names=[layer], class_dict=None, use_cuda=False,
+                                 input_spatial_size=(224, 224), normalizePerFrame=True, archType="I3D")
+        cam, output = gc(x, None)
+        out[f'{layer}_cam_small'] = cam[:, ::8, ::8]
+        out[f'{layer}_cam_shape'] = np.array(cam.shape)
+        out[f'{layer}_weights'] = np.mean(gc.extractor.get_gradients()[-1].numpy(), axis=(2, 3, 4))[0]
+        out[f'{layer}_output'] = output.detach().numpy()
+    save('gradcam_layers', **out)
+
+
 def gen_ingest():
     """Clip ingest: the reference loader classes on small synthetic JPEG
     folders.  The fixture holds the JPEG bytes themselves (a few KB) and the loader output."""
@@ -633,7 +651,7 @@ def gen_ingest():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest',
-                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz', 'clstm_seq']
+                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz', 'clstm_seq', 'gradcam_layers']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

@@ -262,3 +262,21 @@ def test_drivers_run_on_a_jpeg_folder(tmp_path, monkeypatch):
     drv.main(["-c", str(cfg), "--msl", "", "--optIter", "3", "--subDir", "jpg"])
     tm = pickle.load(open(tmp_path / "results" / "allTimeMaskResults_jpg_None_.p", "rb"))
     assert sorted(r['video_id'] for r in tm) == ["101", "202"] and sorted(r['true_class'] for r in tm) == [3, 5]
+
+
+def test_gradcam_video_other_layer_and_refusals(model, golden):
+    import ivf_lib as L
+    import ivf_recipe as R
+    from grad_cam_videos import GradCamVideo
+    g = golden('gradcam_layers')
+    x = torch.from_numpy(R.clip(11))[None].cuda()
+    gc = GradCamVideo(model=model, target_layer_names=['Mixed_4f'], class_dict=None, use_cuda=True,
+                      input_spatial_size=(224, 224), normalizePerFrame=True, archType="I3D")
+    cam, output = gc(x, None)
+    assert np.max(np.abs(cam[:, ::8, ::8] - g['Mixed_4f_cam_small'])) < 1e-3
+    feats, _ = gc.extractor(x)
+    assert tuple(feats[0].shape) == (1, 832, 4, 14, 14)
+    for bad in (['Mixed_4f', 'Mixed_5c'], ['Mixed_4f.b0'], ['nope']):
+        with pytest.raises(L.IvfError):
+            GradCamVideo(model=model, target_layer_names=bad, class_dict=None, use_cuda=True,
+                         input_spatial_size=(224, 224), archType="I3D")(x, None)

@@ -65,8 +65,10 @@ def _check_forward_backward(eng, tag, shape, g, clip_id=7):
     sample, ref = dxn.ravel()[g[f'{tag}_dx_idx']].astype(np.float64), g[f'{tag}_dx_val'].astype(np.float64)
     l2 = np.linalg.norm(sample - ref) / np.linalg.norm(ref)
     note(f"whole-chain dx {tag} {eng.math}: sampled L2 {l2:.2e}, max {rel_err(sample, ref):.2e}")
+    # measured (profiles/r02_parity_measured.txt): CPU vs CPU 0.3 % L2 / 1.0 % max; exact-fp32 MFMA 0.6-1.1 % /
+    # 1.3-1.7 %; split-bf16 2.3-3.1 % / 2.8-7.7 % (its ~1e-5 arithmetic noise flips more near-ties)
     assert l2 < (3e-2 if eng.math == "fp32" else 5e-2)
-    assert rel_err(sample, ref) < 8e-2
+    assert rel_err(sample, ref) < (4e-2 if eng.math == "fp32" else 1e-1)
     assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
     # per-frame sums cancel to ~1e-6 of the gradient's norm: the most tie-sensitive figure here
@@ -400,3 +402,24 @@ def test_reverse_mask_search_s16(s16, golden):
     assert np.max(np.abs(torch.sigmoid(raw)[0].cpu().numpy() - g['s16_mask'])) < 2e-3
     with pytest.raises(UnboundLocalError):
         s16.search(x, [target], raw, 0.01, 0.02, 1, mode='blur')     # as mask.py:57 fails
+
+
+@pytest.mark.parametrize("layer", ['Conv3d_2c_3x3', 'MaxPool3d_3a_3x3', 'Mixed_3c', 'Mixed_4c', 'Mixed_4f', 'Mixed_5b'])
+def test_gradcam_other_target_layers(s16, layer, golden):
+    """GradCamVideo on any endpoint (grad-cam.py:23-54) vs the reference's own output: conv endpoint, pool
+    endpoint, Inception endpoints feeding a (gated) max-pool and feeding the next module."""
+    import ivf_recipe as R
+    g = golden('gradcam_layers')
+    x = torch.from_numpy(R.clip(11))[None].cuda()
+    cam, probs = s16.gradcam(x, None, per_frame=True, layer=layer)
+    cam = cam[0].cpu().numpy()
+    assert list(cam.shape) == g[f'{layer}_cam_shape'].tolist() == [16, 224, 224]
+    assert rel_err(probs.cpu().numpy(), g[f'{layer}_output']) < 1e-3
+    ref, got = g[f'{layer}_cam_small'], cam[:, ::8, ::8]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    note(f"gradcam s16 target {layer} {s16.math}: max|d| {np.max(np.abs(got[ok] - ref[ok])):.2e}")
+    assert ok.any() and np.max(np.abs(got[ok] - ref[ok])) < 1e-3
+    # the ordinary passes are untouched by the ungated Grad-CAM pass before them
+    p2 = s16.forward(x)
+    assert torch.equal(p2, probs)

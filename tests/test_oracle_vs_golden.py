@@ -316,3 +316,16 @@ def test_clstm_use_entire_seq_matches_reference(golden):
         assert rel_err(y.detach().numpy(), g[f'clip{cid}_probs']) < 1e-5
         y[0, 2].backward()
         assert rel_err(x.grad.numpy().ravel()[g[f'clip{cid}_dx_idx']], g[f'clip{cid}_dx_val']) < 1e-4
+
+
+@pytest.mark.parametrize("layer", ['Conv3d_2c_3x3', 'Mixed_3c', 'Mixed_4f'])
+def test_gradcam_other_target_layers_match_reference(layer, golden):
+    """Target layers other than Mixed_5c (grad-cam.py:23-54): the hook sees the gradient w.r.t. the named
+    module's OUTPUT (ungated by its own ReLU), also below a max-pool (dead windows route to the first cell)."""
+    g = golden('gradcam_layers')
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(11))[None]
+    cam, out, ex = gradcam_ref.gradcam_i3d(x, sd, None, layer=layer)
+    assert list(cam.shape) == g[f'{layer}_cam_shape'].tolist()
+    assert rel_err(ex['weights'], g[f'{layer}_weights']) < 1e-4
+    assert np.allclose(cam[:, ::8, ::8], g[f'{layer}_cam_small'], atol=5e-5, equal_nan=True)
