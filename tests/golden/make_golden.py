@@ -593,7 +593,7 @@ def gen_gradcam_layers():
     out = {}
     m = _i3d(False)
     x = torch.from_numpy(R.clip(11))[None]
-    for layer in ('Conv3d_2c_3x3', 'MaxPool3d_3a_3x3', 'Mixed_3c', 'Mixed_4c', 'Mixed_4f', 'Mixed_5b'):
+    for layer in ('Conv3d_2c_3x3', 'MaxPool3d_3a_3x3', 'Mixed_3c', 'Mixed_4c', 'Mixed_4d', 'Mixed_4e', 'Mixed_4f', 'Mixed_5b'):
         gc = ref_gc.GradCamVideo(model=m, target_layer_names=[layer], class_dict=None, use_cuda=False,
                                  input_spatial_size=(224, 224), normalizePerFrame=True, archType="I3D")
         cam, output = gc(x, None)
