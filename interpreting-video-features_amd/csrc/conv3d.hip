@@ -589,8 +589,6 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   }
   if (d->math == 0) IVF_CHECK_ARG(a.ldw == a.K, "conv3d: internal ldw");
   static const bool no_halo = getenv("IVF_NO_HALO") != nullptr;   // A/B switch for measurements
-  static const int dbg = getenv("IVF_DBG") ? atoi(getenv("IVF_DBG")) : 0;
-  a.dbg = dbg;
   if (d->variant != IVF_CONV_AUTO) {
     // explicit kernel variant (set by the plan's tuner)
     if (d->variant == IVF_CONV_PIX4) {

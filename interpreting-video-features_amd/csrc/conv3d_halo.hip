@@ -21,7 +21,6 @@ namespace ivf {
 // the A operand and the epilogue agree; the choice per halo width minimises LDS bank conflicts
 // of the 16-byte fragment reads (rows are 80 B apart; 3-way with the natural order, 2-way so).
 __device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
-  // hw_pitch == 0 selects the natural order (ablation switch)
   const int b0 = p & 1, b1 = (p >> 1) & 1, b2 = (p >> 2) & 1, b3 = (p >> 3) & 1, b4 = (p >> 4) & 1;
   const int half = p >> 5;
   int hl, ww;
@@ -134,7 +133,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   for (int i = 0; i < TM; ++i) {
     int r = wm * WROWS + i * 32 + li;
     int pt, ph, pw;
-    box_pos<TT, TH, TW>(r, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+    box_pos<TT, TH, TW>(r, HW, &pt, &ph, &pw);
     arow[i] = pt * PS + ph * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
@@ -199,12 +198,6 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       }
     }
   };
-  // A fragments do not depend on the per-tap barrier (the halo is static within a chunk), so
-  // the 8-wave variants keep the NEXT tap's A fragments in flight under this tap's MFMAs and
-  // read both k-steps of a tap up front: one exposed LDS latency per tap (the weight
-  // fragments) instead of two full ones.  The 16-wave variants have no registers for that.
-  constexpr bool PIPE = false;   // measured slower (register arrays spill to scratch); kept for later tuning
-  bf16x8 pah[2][TM], pal[2][TM];   // prefetched A fragments of the upcoming tap, both k-steps
   auto tap_offset = [&](int tap) {
     const int kt = tap / khw;
     const int rem = tap - kt * khw;
@@ -212,52 +205,12 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     const int kw = rem - kh * a.kW;
     return (kt * PS + kh * HW + kw) * ROWB;
   };
-  auto load_a = [&](int step) {
-    const int tap = step + wk * nsteps;
-    if (tap >= ntaps) return;
-    const int toff = tap_offset(tap);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int off = arow[i] * ROWB + toff + ks * 32 + 16 * lh;
-        pah[ks][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        pal[ks][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
-      }
-  };
   auto mma_tap = [&](int step, int buf, int nks) {
     const int tap = step + wk * nsteps;
     if (tap >= ntaps) return;
     const unsigned char* bh = b_base + (size_t)(buf * KS + wk) * 2 * BN * ROWB;
     const unsigned char* bl = bh + (size_t)BN * ROWB;
-    if constexpr (PIPE) {
-      bf16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) { fah[ks][i] = pah[ks][i]; fal[ks][i] = pal[ks][i]; }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          int off = (wn * WCOLS + j * 32 + li) * ROWB + ks * 32 + 16 * lh;
-          fbh[ks][j] = *reinterpret_cast<const bf16x8*>(bh + off);
-          fbl[ks][j] = *reinterpret_cast<const bf16x8*>(bl + off);
-        }
-      }
-      if (step + 1 < nsteps) load_a(step + 1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks < nks) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbl[ks][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
-            }
-        }
-      }
-    } else {
+    {
       const int toff = tap_offset(tap);
       for (int ks = 0; ks < nks; ++ks) {
         bf16x8 fah[TM], fal[TM];
@@ -283,12 +236,9 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     }
   };
 
-  // halo staging split in two (issue early / write late): 8 float4 groups per halo row
-  // (16-wave variants have no registers to spare and enough waves to hide the latency: they
-  // stage synchronously in batches of 4 loads)
-  constexpr bool ASYNC = false;   // measured: issuing the next halo early buys nothing and costs 40+ registers
-  constexpr int HRMAX = (TT + 3) * (TH + 3) * (TW + 3);
-  constexpr int NSTG = ASYNC ? (HRMAX * G4 + NT - 1) / NT : 4;
+  // halo staging, synchronous in batches of 4 loads per thread: 8 float4 groups per halo row (issuing the
+  // next chunk's halo early was measured: nothing gained, 40+ registers lost)
+  constexpr int NSTG = 4;
   float4 stg[NSTG];
   // (rows are visited in perm8 order, so the item range is padded to whole blocks of 8 rows)
   const int ngroups = BKH == 32 ? ((HR + 7) & ~7) * G4 : HR * G4;
@@ -303,7 +253,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         if (row >= HR) row = -1;
         int c = c0 + 4 * g;
         int pos = row >= 0 ? rowoff[row] : -1;
-        if (pos >= 0 && c < a.Cin && !(a.dbg & 512))
+        if (pos >= 0 && c < a.Cin)
           v = *reinterpret_cast<const float4*>(a.in + (size_t)pos * a.in_ld + a.in_coff + c);
       }
       stg[u] = v;
@@ -330,27 +280,14 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #pragma unroll
     for (int u = 0; u < PF; ++u)
       if (u < nsteps) load_b(u, u, c0);
-    const bool async = ASYNC && !(a.dbg & 64);
-    if (async && c0 == 0) stage_load(0);
     __syncthreads();   // everyone is done with the previous chunk's halo and weight buffers
-    if (async) {
-      stage_store();
-    } else if (ASYNC) {
+    for (stage_base = 0; stage_base < ngroups; stage_base += NSTG * NT) {
       stage_load(c0);
       stage_store();
-    } else {
-      for (stage_base = 0; stage_base < ngroups; stage_base += NSTG * NT) {
-        stage_load(c0);
-        stage_store();
-      }
-      stage_base = 0;
     }
+    stage_base = 0;
     store_b(0, 0);
     __syncthreads();
-    if constexpr (PIPE) load_a(0);
-    // the next chunk's halo loads fly under this chunk's MFMAs (registers only; LDS is rewritten
-    // after the barrier that ends the chunk)
-    if (async && c0 + BKH < a.Cin) stage_load(c0 + BKH);
 
     const int cw = min(BKH, a.Cin - c0);
     const int nks = (cw + 15) >> 4;
@@ -361,10 +298,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       constexpr int u = decltype(U)::value;
       const int tap = tap0 + u;   // step index within the chunk
       if (tap < nsteps) {
-        if (tap + PF < nsteps && !(a.dbg & 8)) load_b(u, tap + PF, c0);
-        if (!(a.dbg & 32)) mma_tap(tap, tap & 1, nks);
-        if (tap + 1 < nsteps && !(a.dbg & 8)) store_b((u + 1) % PF, (tap + 1) & 1);
-        if (!(a.dbg & 16)) __syncthreads();
+        if (tap + PF < nsteps) load_b(u, tap + PF, c0);
+        mma_tap(tap, tap & 1, nks);
+        if (tap + 1 < nsteps) store_b((u + 1) % PF, (tap + 1) & 1);
+        __syncthreads();
       }
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
@@ -405,7 +342,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   // 32-byte pieces.  Park the tile in LDS as [2TT][16][16][4] and write whole 256-byte pixel
   // rows instead.
   if (TH == 8 && TW == 8 && BN == 32 && a.d2s && a.Cout == 32 && a.bsT == 2 && a.bsH == 2 && a.bsW == 2 && !a.accumulate && !a.relu &&
-      a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && !(a.dbg & 1024)) {
+      a.dC == 4 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0) {
     float* ot = reinterpret_cast<float*>(smem);
     if (wk == 0) {
       const int n = wn * WCOLS + li;          // TN == 1 for BN == 32
@@ -417,7 +354,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           int bt, bh, bw;
-          box_pos<TT, TH, TW>(row, (a.dbg & 128) ? 0 : HW, &bt, &bh, &bw);
+          box_pos<TT, TH, TW>(row, HW, &bt, &bh, &bw);
           const int tt2 = 2 * bt + pt, hh2 = 2 * bh + ph, ww2 = 2 * bw + pw;
           ot[((tt2 * 16 + hh2) * 16 + ww2) * 4 + c] = acc[i][0][r];
         }
@@ -433,22 +370,11 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   }
   if (wk != 0) return;
 
-  if (a.dbg & 256) {   // ablation: no epilogue (a data-dependent store keeps the accumulators alive)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 12345.678f) a.out[0] = t;
-    return;
-  }
   conv_epilogue<TM, TN>(
       a, acc,
       [&](int row) {
         int pt, ph, pw;
-        box_pos<TT, TH, TW>(row, (a.dbg & 128) ? 0 : HW, &pt, &ph, &pw);
+        box_pos<TT, TH, TW>(row, HW, &pt, &ph, &pw);
         int t = t0 + pt, h = h0 + ph, w = w0 + pw;
         if (t >= a.To || h >= a.Ho || w >= a.Wo) return -1;
         return ((b * a.To + t) * a.Ho + h) * a.Wo + w;

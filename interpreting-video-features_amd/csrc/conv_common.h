@@ -31,7 +31,6 @@ struct ConvKArgs {
   const unsigned short* wbf;
   int ldw;
   long w_lo_off;
-  int dbg;   // ablation switches for measurements (IVF_DBG env; 0 in normal use)
   // second input for 1x1x1 convs: channels [K0, Cin) of the GEMM K dimension come from here
   // (same positions, own row length / channel offset) -- lets one backward GEMM consume the
   // gradients of several branches that live in different buffers

@@ -1,6 +1,6 @@
 """1x1x1 conv timing with the epilogue forms of the backward pass (dev tool)."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import torch, ivf_lib as L
 lib = L.lib()

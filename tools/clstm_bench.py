@@ -1,6 +1,6 @@
 """ConvLSTM (BASELINE configs[3]) mask-search throughput: clips/s for N=100 iterations."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import numpy as np, torch
 import ivf_engine, ivf_recipe as R, ivf_search

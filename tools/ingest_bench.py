@@ -1,6 +1,6 @@
 """Clip ingest kernel timing (dev tool): uint8 [B,16,224,224,3] -> fp32, both layouts."""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import torch, ivf_ingest
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

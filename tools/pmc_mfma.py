@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
               --kernel-trace --output-format csv -d D -- python3 bench.py ...
-    python tools_pmc_mfma.py D out.json
+    python tools/pmc_mfma.py D out.json
 
 mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs).  MFMA_BUSY is summed over
 all SIMDs and counts 32 cycles per v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md; checked: the stem

@@ -1,5 +1,5 @@
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 import torch, ivf_lib as L
 lib = L.lib()

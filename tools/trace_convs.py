@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer view of one search iteration from a rocprofv3 kernel trace (dev tool)."""
-import csv, sys
-sys.path.insert(0, 'interpreting-video-features_amd')
+import csv, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'interpreting-video-features_amd'))
 import ivf_arch as arch
 path, B = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))

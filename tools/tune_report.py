@@ -5,7 +5,7 @@ import collections
 import os
 import re
 import sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 log = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/tune.log"
