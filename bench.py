@@ -40,7 +40,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
              "bf16x3": "bf16 dense MFMA (v_mfma_f32_32x32x16_bf16); every algorithmic FLOP costs 3 MFMA FLOPs "
                        "in the split-bf16 mode, so the fp32-equivalent ceiling is 833 TFLOP/s"}
-NCLASS = 48
+NCLASS = 64
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 
@@ -194,7 +194,7 @@ def collect_roofline(L, eng, B):
     traffic, src = None, None
     try:
         pm = json.load(open(PMC_FILE))
-        ent = pm["kernels"].get(name(dom))
+        ent = pm["kernels"].get(name(dom).replace(" ", ""))
         if ent and pm.get("batch") == B and abs(ent["algorithmic_gflop_per_launch"] - gflop) < 0.02 * gflop:
             traffic = ent["hbm_bytes_per_launch"]
             src = ("profiles/r02_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "

@@ -156,7 +156,7 @@ typedef struct {
 #define IVF_CONV_AUTO 0
 #define IVF_CONV_IGEMM_BASE 1
 #define IVF_CONV_HALO_BASE 16
-#define IVF_CONV_PIX4 47 /* 4-channel-pixel strided kernel (the stem): split-bf16, Cin = in_ld = 4, stride (1|2, 2, 2), k <= 7 */
+#define IVF_CONV_PIX4 15 /* 4-channel-pixel strided kernel (the stem): split-bf16, Cin = in_ld = 4, stride (1|2, 2, 2), k <= 7 */
 int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_ids);
 
 /* out = epilogue(conv(in, w_packed)): v = acc*scale[n] + shift[n] (NULL = 1 / 0);
@@ -426,7 +426,7 @@ int ivf_viz_dots(unsigned char* img, const float* mask_snapped, int T, int H, in
  * IVF_PROFILE_CLASSES entries indexed by kernel variant id (IVF_CONV_IGEMM_BASE + tile for
  * fp32, +3 for split-bf16; IVF_CONV_HALO_BASE + i): summed kernel milliseconds, launch count
  * and algorithmic FLOPs of the sampled launches. */
-#define IVF_PROFILE_CLASSES 48
+#define IVF_PROFILE_CLASSES 64
 int ivf_profile_enable(int every, int max_launches);
 int ivf_profile_disable(void);
 int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);

@@ -435,7 +435,11 @@ int conv_halo_supported(const ConvKArgs& a) {
 // 4 x 4 x 14 boxes (224 rows = 7 MFMA row tiles; exact on 28- and 14-wide maps):
 // 23: 192  32 x 96  1     24: 128  32 x 64  1     25:  96  32 x 96  1     26:  64  32 x 64  1
 // 27:  32  32 x 32  1     28:  64  32 x 32  1     29:  32  32 x 32  2     30: 128  32 x 128 1
-int conv_halo_num_variants() { return 31; }
+// narrow outputs, 2-frame boxes with 16-channel chunks (two or three workgroups per CU: one's per-tap barrier
+// and LDS round trip hide under another's MFMAs -- what the 32-column stem backward-data is short of):
+// 31: 2 32 64 x 32 2    32: 2 32 32 x 32 2    33: 2 32 32 x 32 1    34: 2 64 32 x 64 2    35: 2 64 64 x 64 2
+// 36: 4 32 64 x 32 2 (16)   37: 4 32 32 x 32 2 (16)
+int conv_halo_num_variants() { return 38; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -470,6 +474,13 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 28: return launch_halo<4, 64, 32, 32, 1, 32, 4, 14>(a, 28, s);
     case 29: return launch_halo<4, 32, 32, 32, 2, 32, 4, 14>(a, 29, s);
     case 30: return launch_halo<4, 128, 32, 128, 1, 32, 4, 14>(a, 30, s);
+    case 31: return launch_halo<2, 32, 64, 32, 2, 16>(a, 31, s);
+    case 32: return launch_halo<2, 32, 32, 32, 2, 16>(a, 32, s);
+    case 33: return launch_halo<2, 32, 32, 32, 1, 16>(a, 33, s);
+    case 34: return launch_halo<2, 64, 32, 64, 2, 16>(a, 34, s);
+    case 35: return launch_halo<2, 64, 64, 64, 2, 16>(a, 35, s);
+    case 36: return launch_halo<4, 32, 64, 32, 2, 16>(a, 36, s);
+    case 37: return launch_halo<4, 32, 32, 32, 2, 16>(a, 37, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

@@ -5,9 +5,14 @@
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d B -- python3 bench.py ...
     python tools/pmc_traffic.py A B <batch> out.json
 
+    python tools/pmc_traffic.py A B <batch> out.json [bench_line.json]
+
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (HBM
-section: gfx950 counts 128-byte requests as 64).  Only launches after the autotune phase
-(from the first mask_reg_kernel on) are counted.
+section: gfx950 counts 128-byte requests as 64).  Only the launches of the search iterations
+(first mask_reg_kernel .. last search_step_kernel) are counted -- the launch mix bench.py's
+roofline samples.  With the JSON line bench.py printed in one of the passes, the dominant
+kernel's entry also records its algorithmic GFLOP per launch: bench.py only quotes `traffic` for
+a run whose dominant kernel has the same figure (same template on the same layers).
 """
 import csv, glob, json, os, re, sys
 from collections import defaultdict
@@ -25,8 +30,9 @@ def per_kernel(folder, counter):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     start = next(i for i, r in enumerate(rows) if "mask_reg_kernel" in r["Kernel_Name"])
+    stop = max(i for i, r in enumerate(rows) if "search_step_kernel" in r["Kernel_Name"])
     acc = defaultdict(lambda: [0.0, 0])
-    for r in rows[start:]:
+    for r in rows[start:stop + 1]:      # the search iterations only: the launch mix bench.py samples
         k = short(r["Kernel_Name"])
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
@@ -35,6 +41,7 @@ def per_kernel(folder, counter):
 
 def main():
     fa, fb, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    bench_line = sys.argv[5] if len(sys.argv) > 5 else None
     fetch, write = per_kernel(fa, "FETCH_SIZE"), per_kernel(fb, "WRITE_SIZE")
     kernels = {}
     for k in fetch:
@@ -48,6 +55,12 @@ def main():
                       "fetch_kb_raw_per_launch": int(fkb), "write_kb_per_launch": int(wkb)}
         if nf != nw:
             kernels[k]["launches_write_pass"] = nw
+    if bench_line:
+        txt = [ln for ln in open(bench_line) if ln.startswith("{")][-1]
+        roof = json.loads(txt)["roofline"]
+        kn = re.sub(r"\s+", "", roof["kernel"])
+        if kn in kernels:
+            kernels[kn]["algorithmic_gflop_per_launch"] = roof["algorithmic_gflop_per_launch"]
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kernels.values())
     doc = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
                   "command (split-bf16); launches from the first search iteration on (after autotune); "

@@ -15,7 +15,7 @@ os.environ["IVF_TUNE_LOG"] = log
 import ivf_engine, ivf_recipe as R   # noqa: E402
 eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=B, softmax=True)
 eng.load_state_dict(R.i3d_state_dict(num_classes=174))
-fam = lambda v: "pix4" if v == 47 else "halo" if v >= 16 else "igemm"
+fam = lambda v: "pix4" if v == 15 else "halo" if v >= 16 else "igemm"
 best = collections.OrderedDict()
 for ln in open(log):
     m = re.match(r"(\S+) (\S+) b=(\d+) variant=(\d+) ms=([\d.]+) gflop=([\d.]+)", ln)
