@@ -168,44 +168,58 @@ def cpu_baseline(n_iter_total, sample_iters, lam1, lam2, threads, budget_s=40.0)
 
 
 def collect_roofline(L, eng, B):
-    """Per-kernel-template HIP-event sample of the conv launches of the timed region -> roofline object
-    for the dominant one."""
+    """HIP-event sample of the conv launches of the timed region -> roofline object for the dominant LAUNCH
+    SITE (one convolution of the plan in one direction: a kernel template may serve several layers, so the
+    site is what has a definite algorithmic size)."""
     import numpy as np
+    lib = L.lib()
+    ns = lib.ivf_i3d_num_sites(eng._h)
+    s_ms = (ctypes.c_double * ns)()
+    s_n = (ctypes.c_longlong * ns)()
+    s_fl = (ctypes.c_double * ns)()
+    s_var = (ctypes.c_int * ns)()
+    L.check(lib.ivf_profile_collect_sites(s_ms, s_n, s_fl, s_var, ns))
     ms = (ctypes.c_double * NCLASS)()
     launches = (ctypes.c_longlong * NCLASS)()
     flops = (ctypes.c_double * NCLASS)()
-    L.check(L.lib().ivf_profile_collect(ms, launches, flops))
-    L.check(L.lib().ivf_profile_disable())
+    L.check(lib.ivf_profile_collect(ms, launches, flops))
+    L.check(lib.ivf_profile_disable())
     if sum(launches) == 0:
         return None
-    name = lambda v: L.lib().ivf_profile_class_name(v).decode() or f"class{v}"
+    name = lambda v: lib.ivf_profile_class_name(v).decode() or f"class{v}"
     math = eng.math
     peak = PEAK_TFLOPS[math]
-    dom = int(np.argmax([ms[v] for v in range(NCLASS)]))
-    avg_ms = ms[dom] / launches[dom]
-    gflop = flops[dom] / launches[dom] / 1e9
+    dom = int(np.argmax([s_ms[i] for i in range(ns)]))
+    buf = ctypes.create_string_buffer(64)
+    L.check(lib.ivf_i3d_site_name(eng._h, dom, buf))
+    site = buf.value.decode()
+    v = int(s_var[dom])
+    avg_ms = s_ms[dom] / s_n[dom]
+    gflop = s_fl[dom] / s_n[dom] / 1e9
     achieved = gflop / avg_ms          # GFLOP / ms = TFLOP/s
-    tot_ms = sum(ms[v] for v in range(NCLASS))
-    tot_fl = sum(flops[v] for v in range(NCLASS))
-    shares = {name(v): round(ms[v] / tot_ms, 3) for v in range(NCLASS) if launches[v] > 0}
-    # HBM bytes per launch from this round's PMC passes -- only when they were taken on the SAME launch
-    # mix: same kernel template, same batch, same algorithmic work per launch (the tuner can give a
-    # template to different layers from run to run); otherwise null
+    tot_ms = sum(ms[i] for i in range(NCLASS))
+    tot_fl = sum(flops[i] for i in range(NCLASS))
+    shares = {name(i): round(ms[i] / tot_ms, 3) for i in range(NCLASS) if launches[i] > 0}
+    # HBM bytes per launch of THAT site from this round's PMC passes (profiles/), taken on the same batch
+    # size and the same kernel template; otherwise null
     traffic, src = None, None
     try:
         pm = json.load(open(PMC_FILE))
-        ent = pm["kernels"].get(name(dom).replace(" ", ""))
-        if ent and pm.get("batch") == B and abs(ent["algorithmic_gflop_per_launch"] - gflop) < 0.02 * gflop:
+        ent = pm["sites"].get(site)
+        if ent and pm.get("batch") == B and ent["kernel"] == name(v).replace(" ", ""):
             traffic = ent["hbm_bytes_per_launch"]
             src = ("profiles/r02_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                   "FETCH doubled per the gfx950 rule; same template, batch and GFLOP per launch as this run)")
+                   "FETCH doubled per the gfx950 rule; same launch site, kernel template and batch as this run)")
     except (OSError, ValueError, KeyError):
         pass
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
-        "kernel": name(dom), "avg_launch_ms": round(avg_ms, 4), "sampled_launches": int(launches[dom]),
-        "algorithmic_gflop_per_launch": round(gflop, 3),
+        "kernel": name(v), "launch_site": site, "avg_launch_ms": round(avg_ms, 4),
+        "sampled_launches": int(s_n[dom]), "algorithmic_gflop_per_launch": round(gflop, 3),
+        # rocprofv3 --stats averages per kernel NAME, i.e. over every site the template serves: the figure to
+        # compare with profiles/r02_bench_kernel_stats.csv
+        "kernel_name_avg_launch_ms": round(ms[v] / launches[v], 4), "kernel_name_sampled_launches": int(launches[v]),
         "mfma_passes_per_algorithmic_flop": 3 if math == "bf16x3" else 1,
         "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                              "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),

@@ -430,6 +430,13 @@ int ivf_viz_dots(unsigned char* img, const float* mask_snapped, int T, int H, in
 int ivf_profile_enable(int every, int max_launches);
 int ivf_profile_disable(void);
 int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);
+/* The same sample per launch SITE of an I3D plan (site = 2 * op index + direction; names from
+ * ivf_i3d_site_name, count from ivf_i3d_num_sites): summed milliseconds, launches, algorithmic FLOPs and the
+ * kernel variant that served the site.  Does not reset the sample: call it before ivf_profile_collect. */
+int ivf_profile_collect_sites(double* kernel_ms_host, long long* launches_host, double* flops_host,
+                              int* variant_host, int max_sites);
+int ivf_i3d_num_sites(const ivf_i3d_t* net);
+int ivf_i3d_site_name(const ivf_i3d_t* net, int site, char* name64);
 /* Kernel template instance behind a class id ("" until that class has been launched). */
 const char* ivf_profile_class_name(int cls);
 

@@ -416,6 +416,7 @@ static int check_ready(const ivf_i3d* n, int b) {
 
 static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream_t s) {
   for (const Op& o : n->ops) {
+    prof_set_site(o.type == Op::CONV ? 2 * (int)(&o - n->ops.data()) : -1);
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
@@ -459,6 +460,7 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
     if (n->cam_buf >= 0 && o.dst == n->cam_buf) break;   // Grad-CAM pass: the target's gradient is complete
     if (o.bwd_skip) continue;
     const float* gate = (o.bwd_mask && o.src != n->cam_buf) ? n->act(o.src) : nullptr;
+    prof_set_site(o.type == Op::CONV ? 2 * i + 1 : -1);
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
@@ -781,6 +783,22 @@ extern "C" double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net) {
   if (net)
     for (const Op& o : net->ops) f += o.flops_per_clip;
   return f;
+}
+
+extern "C" int ivf_i3d_num_sites(const ivf_i3d_t* net) { return net ? 2 * (int)net->ops.size() : 0; }
+
+extern "C" int ivf_i3d_site_name(const ivf_i3d_t* net, int site, char* name64) {
+  IVF_CHECK_ARG(net && name64 && site >= 0 && site < 2 * (int)net->ops.size(), "i3d_site_name: bad site");
+  const Op& o = net->ops[site >> 1];
+  IVF_CHECK_ARG(o.type == Op::CONV, "i3d_site_name: site %d is not a convolution", site);
+  const ConvLayer& L = net->convs[o.conv];
+  std::string nm = L.name;
+  if (!(site & 1) && o.fwd_group) nm = L.name.substr(0, L.name.rfind('.')) + ".b1a|b2a";
+  if ((site & 1) && o.bwd_fused) nm = L.name.substr(0, L.name.rfind('.')) + ".b0|b1a|b2a";
+  nm += (site & 1) ? " backward-data" : " forward";
+  strncpy(name64, nm.c_str(), 63);
+  name64[63] = 0;
+  return IVF_OK;
 }
 
 extern "C" int ivf_i3d_num_conv_ops(const ivf_i3d_t* net) {

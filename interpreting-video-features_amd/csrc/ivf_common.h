@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...);
 // launch profiler (ivf_common.hip)
 void prof_set_iteration(int it);
 void prof_set_flops(double algorithmic_flops);
+void prof_set_site(int site);   // launch site of the next sampled launches (2 * op index + direction), -1 none
 bool prof_begin(hipStream_t s, int variant);
 void prof_end(hipStream_t s);
 void prof_name(int variant, const char* fmt, ...);   // kernel name of a profiler class (first call wins)

@@ -28,8 +28,10 @@ struct Prof {
   size_t cap = 0, used = 0;
   std::vector<hipEvent_t> ev;          // 2 per sampled launch
   std::vector<int> variant;
+  std::vector<int> site;
   std::vector<double> flops;
   double next_flops = 0.0;
+  int next_site = -1;
 };
 static Prof g_prof;
 static char g_prof_names[IVF_PROFILE_CLASSES][96];
@@ -42,6 +44,7 @@ void prof_name(int variant, const char* fmt, ...) {
 }
 void prof_set_iteration(int it) { g_prof.active = g_prof.enabled && it >= 0 && (it % g_prof.every == 0); }
 void prof_set_flops(double f) { g_prof.next_flops = f; }
+void prof_set_site(int site) { g_prof.next_site = site; }
 bool prof_begin(hipStream_t s, int variant) {
   Prof& p = g_prof;
   if (!p.active || p.used >= p.cap) return false;
@@ -52,8 +55,10 @@ bool prof_begin(hipStream_t s, int variant) {
     p.ev.push_back(b);
   }
   p.variant.resize(p.used + 1);
+  p.site.resize(p.used + 1);
   p.flops.resize(p.used + 1);
   p.variant[p.used] = variant;
+  p.site[p.used] = p.next_site;
   p.flops[p.used] = p.next_flops;
   (void)hipEventRecord(p.ev[2 * p.used], s);
   return true;
@@ -84,6 +89,28 @@ extern "C" int ivf_profile_disable(void) {
 // Kernel (template instance) behind a profiler class id; "" until that class has launched.
 extern "C" const char* ivf_profile_class_name(int cls) {
   return (cls >= 0 && cls < IVF_PROFILE_CLASSES) ? ivf::g_prof_names[cls] : "";
+}
+
+// The same sample summed per launch SITE (a convolution of the plan in one direction: site = 2 * op index
+// + direction, see ivf_i3d_site_name): kernel_ms[s], launches[s], flops[s], variant[s] for s < max_sites.
+// Does not reset the sample; call before ivf_profile_collect.
+extern "C" int ivf_profile_collect_sites(double* kernel_ms, long long* launches, double* flops, int* variant,
+                                         int max_sites) {
+  IVF_CHECK_ARG(kernel_ms && launches && flops && variant && max_sites > 0, "profile_collect_sites: bad args");
+  ivf::Prof& p = ivf::g_prof;
+  for (int v = 0; v < max_sites; ++v) { kernel_ms[v] = 0.0; launches[v] = 0; flops[v] = 0.0; variant[v] = -1; }
+  for (size_t i = 0; i < p.used; ++i) {
+    const int st = p.site[i];
+    if (st < 0 || st >= max_sites) continue;
+    IVF_CHECK_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
+    float ms = 0.f;
+    IVF_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    kernel_ms[st] += ms;
+    launches[st] += 1;
+    flops[st] += p.flops[i];
+    variant[st] = p.variant[i];
+  }
+  return IVF_OK;
 }
 
 // Sums per kernel variant id v in [0,IVF_PROFILE_CLASSES): kernel_ms[v], launches[v], flops[v];

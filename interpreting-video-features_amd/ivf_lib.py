@@ -120,6 +120,10 @@ _SIGS = {
     "ivf_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),
                                     POINTER(ctypes.c_double)]),
     "ivf_profile_class_name": (c_char_p, [_I]),
+    "ivf_profile_collect_sites": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_longlong),
+                                          POINTER(ctypes.c_double), POINTER(c_int), _I]),
+    "ivf_i3d_num_sites": (c_int, [_P]),
+    "ivf_i3d_site_name": (c_int, [_P, _I, c_char_p]),
 }
 
 # csrc/convlstm.hip

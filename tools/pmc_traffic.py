@@ -39,6 +39,25 @@ def per_kernel(folder, counter):
     return acc
 
 
+def stem_backward(folder, counter):
+    """The stem's backward-data launches: in every search iteration the LAST conv3d_* dispatch before the
+    freeze backward (the plan's backward runs the ops in reverse; Conv3d_1a_7x7 is the first op)."""
+    f = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    tot, n, kern, last = 0.0, 0, None, None
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if k.startswith("conv3d_"):
+            last = r
+        elif k.startswith("freeze_bwd") and last is not None:
+            tot += float(last["Counter_Value"])
+            n += 1
+            kern = short(last["Kernel_Name"])
+            last = None
+    return tot / max(n, 1), n, kern
+
+
 def main():
     fa, fb, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     bench_line = sys.argv[5] if len(sys.argv) > 5 else None
@@ -62,7 +81,15 @@ def main():
         if kn in kernels:
             kernels[kn]["algorithmic_gflop_per_launch"] = roof["algorithmic_gflop_per_launch"]
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kernels.values())
-    doc = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
+    sites = {}
+    fkb, nf, kf = stem_backward(fa, "FETCH_SIZE")
+    wkb, nw, kw = stem_backward(fb, "WRITE_SIZE")
+    if nf and nw and kf == kw:
+        sites["Conv3d_1a_7x7 backward-data"] = {
+            "kernel": kf, "launches": nf, "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024),
+            "fetch_kb_raw_per_launch": int(fkb), "write_kb_per_launch": int(wkb),
+            "found_as": "last conv3d_* dispatch before each freeze_bwd* dispatch"}
+    doc = {"sites": sites, "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
                   "command (split-bf16); launches from the first search iteration on (after autotune); "
                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM "
                   "(gfx950 counts 128-B requests at 64 B)",
