@@ -238,7 +238,7 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
     eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=B, softmax=True,
                                stride_mod_layers="" if T == 16 else "none", device=dev, math=math)
     eng.load_state_dict(R.i3d_state_dict(num_classes=174), autotune=(rank == 0))
-    if world > 1:
+    if dist is not None:
         # every rank must run the SAME kernel variant per layer (bit-identical per-clip results):
         # rank 0 tunes, one small broadcast installs its choice everywhere
         tune = torch.tensor(eng.get_tuning(), dtype=torch.int32, device=dev)
@@ -259,7 +259,7 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
         return ivf_shard.gather_records(rec, equal_shards=True)    # ONE RCCL all_gather when world > 1
 
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -273,7 +273,7 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -341,9 +341,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # IVF_BENCH_FORCE_DIST=1: run the RCCL path (init, tuning broadcast, record all_gather, MAX all_reduce) with
+    # a world of one -- how the N>1 code is exercised on a one-GPU box
+    use_dist = world > 1 or os.environ.get("IVF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
@@ -385,7 +391,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample_iters, lam1, lam2, host_cores())
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,6 +16,20 @@
 
 namespace ivf {
 
+// Diagnostic build only (make stamps -> libivf_hip_stamps.so, tools/halo_stamps.py): thread 0 of every
+// workgroup adds its cycles per phase to g_halo_stamps; the product build compiles none of it.
+#ifdef IVF_HALO_STAMPS
+__device__ unsigned long long g_halo_stamps[8];
+#define IVF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define IVF_STAMP_RT(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()   // 100 MHz
+#define IVF_STAMP_ADD(slot, t1, t0) \
+  do { if (threadIdx.x == 0) atomicAdd(&g_halo_stamps[slot], (t1) - (t0)); } while (0)
+#else
+#define IVF_STAMP(var) do {} while (0)
+#define IVF_STAMP_RT(var) do {} while (0)
+#define IVF_STAMP_ADD(slot, t1, t0) do {} while (0)
+#endif
+
 // Position (h, w) inside the 8 x 8 plane of a tile for plane-row p in [0,64): two 32-row MFMA
 // tiles (4 h-rows x 8 w each).  Which lane bit feeds which coordinate bit is free as long as
 // the A operand and the epilogue agree; the choice per halo width minimises LDS bank conflicts
@@ -83,7 +97,11 @@ __host__ __device__ inline int halo_plane_rows(int HH, int HW) {
 // the stem's 32-column backward-data need); the two partial sums meet in LDS at the end.
 // BKH = channels per chunk: 32, or 16 to halve the LDS footprint so that TWO workgroups are
 // resident per CU and one's halo staging / weight pipeline overlaps the other's MFMAs.
-template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH, int TH, int TW>
+// TPS = taps per barrier interval ("step"): the weight tiles of TPS taps sit in each LDS buffer and the waves sweep
+// them without meeting.  Every barrier costs the MFMA pipe about 1000 idle cycles (the waves re-issue their fragment
+// reads together; profiles/r02_halo_phase_stamps.txt), which a narrow tile (32 columns: 6 MFMAs per wave per
+// tap) cannot amortise over one tap.
+template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH, int TH, int TW, int TPS>
 __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
                                                                                                 int tilesT,
                                                                                                 int tilesH,
@@ -96,20 +114,22 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   constexpr int ROWB = (BKH + 8) * 2;   // bytes per LDS row per plane (80 / 48: conflict-free 16-byte reads)
   constexpr int G4 = BKH / 4;           // float4 groups per halo row
   constexpr int G8 = BKH / 8;           // 16-byte weight groups per row per plane
-  constexpr int BLOADS = (KS * BN * G8 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
+  constexpr int BLOADS = (TPS * KS * BN * G8 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  IVF_STAMP(st_begin);
+  IVF_STAMP_RT(rt_begin);
   const int HT = TT + a.kT - 1, HH = TH + a.kH - 1, HW = TW + a.kW - 1;
   const int PS = halo_plane_rows<TT, TH, TW>(HH, HW);   // LDS rows per halo plane (>= HH * HW)
   const int HR = HT * PS;
   unsigned char* a_hi = smem;
   unsigned char* a_lo = smem + (size_t)HR * ROWB;
-  unsigned char* b_base = smem + (size_t)2 * HR * ROWB;   // [2 buffers][hi, lo][BN rows]
-  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * KS * BN * ROWB);   // [HR] input offset of a halo row / in_ld, or -1
+  unsigned char* b_base = smem + (size_t)2 * HR * ROWB;   // [2 buffers][TPS taps][KS groups][hi, lo][BN rows]
+  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * TPS * KS * BN * ROWB);   // [HR] input offset of a halo row / in_ld, or -1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tap decode and tile bases stay on the scalar unit
   const int wk = wave / (WM * WN);               // tap group of this wave
   const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
@@ -137,7 +157,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     arow[i] = pt * PS + ph * HW + pw;
   }
   const int ntaps = a.kT * a.kH * a.kW;
-  const int nsteps = (ntaps + KS - 1) / KS;      // tap group g handles taps [g*nsteps, (g+1)*nsteps)
+  const int ntg = (ntaps + KS - 1) / KS;         // tap group g handles taps [g*ntg, (g+1)*ntg)
+  const int nsteps = (ntg + TPS - 1) / TPS;      // barrier intervals per chunk; step s = group-local taps [s*TPS, (s+1)*TPS)
   const int khw = a.kH * a.kW;
   // halo row -> input position (decoded once; the chunk loop only adds the channel offset)
   for (int row = tid; row < HR; row += NT) {
@@ -162,76 +183,148 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   // one tap of MFMAs and there is a single workgroup per CU, so nothing else would hide it) and
   // a double-buffered LDS tile.
   constexpr int PF = 3;
-  uint4 rbh[PF][BLOADS], rbl[PF][BLOADS];
-  auto load_b = [&](int slot, int step, int c0) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rbh[PF][BLOADS], rbl[PF][BLOADS];
+  // Per-thread constants of the weight stream, decoded once: the tap loop only adds the tap and the chunk.  (The
+  // scalar unit is what a narrow tile runs out of: 75 scalar + 28 vector instructions per tap beside 6 MFMAs
+  // measured 53 % scalar-busy at 36 % MFMA-busy on the stem's backward-data.)
+  // Every thread loads every step, from an address clamped into the weight array, with no validity branch and no
+  // zero fill: a slot outside the step, tap range, layer rows or channels holds finite weights of some other
+  // position, which meet staged zeros (channels), are skipped (taps) or land in columns nobody stores (rows).
+  // Straight-line loads are what lets the compiler count them (`s_waitcnt vmcnt(N)`): behind a branch it waited
+  // for vmcnt(0) right after issuing the prefetch, i.e. exposed a full L2 round trip per tap.
+  int b_src[BLOADS];    // element offset min(n, Cout - 1) * ldw into wbf (0 for threads without a slot)
+  int b_dst[BLOADS];    // byte offset in one LDS weight buffer [TPS][KS][hi, lo][BN rows]; -1 = no slot
+  int b_tap[BLOADS];    // sub-tap + group * ntg: tap of step s = s * TPS + b_tap
+  int b_c[BLOADS];      // channel offset inside the chunk
+#pragma unroll
+  for (int q = 0; q < BLOADS; ++q) {
+    const int idx = tid + q * NT;
+    const int sub = idx / (KS * BN * G8);
+    const int r1 = idx - sub * (KS * BN * G8);
+    const int grp = r1 / (BN * G8);
+    const int rem = r1 - grp * (BN * G8);
+    const int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
+    const int n = min(n0 + row, a.Cout - 1);
+    b_src[q] = sub < TPS ? n * a.ldw : 0;
+    b_dst[q] = sub < TPS ? ((sub * KS + grp) * 2 * BN + row) * ROWB + 16 * g2 : -1;
+    b_tap[q] = sub < TPS ? sub + grp * ntg : 0;
+    b_c[q] = 8 * g2;
+  }
+  auto load_b = [&](int slot, int step, int c0) __attribute__((always_inline)) {
+    const int s0 = min(step, nsteps - 1) * TPS;
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
-      int idx = tid + q * NT;
-      int grp = idx / (BN * G8);
-      int rem = idx - grp * (BN * G8);
-      int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
-      int tap = step + grp * nsteps;
-      int n = n0 + row;
-      int c = c0 + 8 * g2;
-      uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-      if (grp < KS && tap < ntaps && n < a.Cout && c < a.Cin) {
-        const unsigned short* p = a.wbf + (size_t)n * a.ldw + (size_t)tap * a.Cin + c;
-        h = *reinterpret_cast<const uint4*>(p);
-        l = *reinterpret_cast<const uint4*>(p + a.w_lo_off);
-      }
-      rbh[slot][q] = h;
-      rbl[slot][q] = l;
+      const int tap = min(s0 + b_tap[q], ntaps - 1);
+      int c = c0 + b_c[q];
+      c = c < a.Cin ? c : 0;
+      const unsigned short* p = a.wbf + (size_t)(b_src[q] + tap * a.Cin + c);
+      rbh[slot][q] = *reinterpret_cast<const u32x4*>(p);
+      rbl[slot][q] = *reinterpret_cast<const u32x4*>(p + a.w_lo_off);
     }
   };
-  auto store_b = [&](int slot, int buf) {
+  auto store_b = [&](int slot, int buf) __attribute__((always_inline)) {
+    unsigned char* bb = b_base + (size_t)buf * (TPS * KS * 2 * BN * ROWB);
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
-      int idx = tid + q * NT;
-      int grp = idx / (BN * G8);
-      int rem = idx - grp * (BN * G8);
-      int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
-      if (grp < KS) {
-        unsigned char* bh = b_base + (size_t)(buf * KS + grp) * 2 * BN * ROWB;
-        unsigned char* bl = bh + (size_t)BN * ROWB;
-        *reinterpret_cast<uint4*>(bh + row * ROWB + 16 * g2) = rbh[slot][q];
-        *reinterpret_cast<uint4*>(bl + row * ROWB + 16 * g2) = rbl[slot][q];
+      if (b_dst[q] >= 0) {
+        *reinterpret_cast<u32x4*>(bb + b_dst[q]) = rbh[slot][q];
+        *reinterpret_cast<u32x4*>(bb + b_dst[q] + BN * ROWB) = rbl[slot][q];
       }
     }
   };
-  auto tap_offset = [&](int tap) {
-    const int kt = tap / khw;
-    const int rem = tap - kt * khw;
-    const int kh = rem / a.kW;
-    const int kw = rem - kh * a.kW;
-    return (kt * PS + kh * HW + kw) * ROWB;
+  // tap -> byte offset of its halo row shift, advanced tap by tap on the scalar unit (no divisions in the loop);
+  // this wave's tap group starts at tap wk * ntg
+  int g_kw, g_kh, g_toff;
+  {
+    const int tap0 = wk * ntg;
+    const int kt = tap0 / khw;
+    const int rem = tap0 - kt * khw;
+    g_kh = rem / a.kW;
+    g_kw = rem - g_kh * a.kW;
+    g_toff = (kt * PS + g_kh * HW + g_kw) * ROWB;
+  }
+  int t_kw = 0, t_kh = 0, t_off = 0;   // running state of the current chunk
+  auto tap_advance = [&]() __attribute__((always_inline)) {
+    t_off += ROWB;
+    if (++t_kw == a.kW) {
+      t_kw = 0;
+      t_off += (HW - a.kW) * ROWB;
+      if (++t_kh == a.kH) {
+        t_kh = 0;
+        t_off += (PS - a.kH * HW) * ROWB;
+      }
+    }
   };
-  auto mma_tap = [&](int step, int buf, int nks) {
-    const int tap = step + wk * nsteps;
-    if (tap >= ntaps) return;
-    const unsigned char* bh = b_base + (size_t)(buf * KS + wk) * 2 * BN * ROWB;
-    const unsigned char* bl = bh + (size_t)BN * ROWB;
-    {
-      const int toff = tap_offset(tap);
-      for (int ks = 0; ks < nks; ++ks) {
-        bf16x8 fah[TM], fal[TM];
+  int abase[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          int off = arow[i] * ROWB + toff + ks * 32 + 16 * lh;
-          fah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-          fal[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+  for (int i = 0; i < TM; ++i) abase[i] = arow[i] * ROWB + 16 * lh;
+  const int bbase = (wn * WCOLS + li) * ROWB + 16 * lh;
+  // One step = the TPS taps of an LDS weight buffer.  Narrow wave tiles (one MFMA tile, 6 MFMAs per tap) run a
+  // software pipeline over the (tap, 16-channel slice) units of the step: the fragments of unit u+1 are in flight
+  // while unit u's MFMAs issue, so a wave exposes one LDS round trip per step instead of two per slice.
+  constexpr int NKS = BKH / 16;
+  constexpr bool PIPELINED = (TM == 1 && TN == 1);
+  auto mma_tap = [&](int step, int buf, int nks) __attribute__((always_inline)) {
+    const int lt0 = step * TPS;
+    const int nsub = min(TPS, min(ntg - lt0, ntaps - wk * ntg - lt0));   // valid taps of this wave's group in the step
+    if (nsub <= 0) return;
+    const unsigned char* bstep = b_base + (size_t)(buf * TPS * KS + wk) * 2 * BN * ROWB;   // + sub * KS * 2 * BN * ROWB
+    if constexpr (PIPELINED) {   // (a partial last chunk runs all NKS slices: channels past Cin are staged as zeros)
+      bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+      auto issue = [&](int slot, int sub, int ks) __attribute__((always_inline)) {
+        const int aoff = abase[0] + t_off + ks * 32;
+        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB + bbase + ks * 32;
+        fah[slot] = *reinterpret_cast<const bf16x8*>(a_hi + aoff);
+        fal[slot] = *reinterpret_cast<const bf16x8*>(a_lo + aoff);
+        fbh[slot] = *reinterpret_cast<const bf16x8*>(bh);
+        fbl[slot] = *reinterpret_cast<const bf16x8*>(bh + (size_t)BN * ROWB);
+      };
+      issue(0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TPS * NKS; ++u) {
+        if (u / NKS < nsub) {
+          if (u + 1 < TPS * NKS && (u + 1) / NKS < nsub) {
+            if ((u + 1) % NKS == 0) tap_advance();
+            issue((u + 1) & 1, (u + 1) / NKS, (u + 1) % NKS);
+          }
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[u & 1], fbh[u & 1], acc[0][0], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[u & 1], fbl[u & 1], acc[0][0], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[u & 1], fbh[u & 1], acc[0][0], 0, 0, 0);
+          // keep the source order: next unit's four fragment reads, then this unit's three MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
+      }
+      tap_advance();
+    } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          int off = (wn * WCOLS + j * 32 + li) * ROWB + ks * 32 + 16 * lh;
-          bf16x8 fbh = *reinterpret_cast<const bf16x8*>(bh + off);
-          bf16x8 fbl = *reinterpret_cast<const bf16x8*>(bl + off);
+      for (int sub = 0; sub < TPS; ++sub) {
+        if (sub >= nsub) break;
+        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB + bbase;
+        const unsigned char* bl = bh + (size_t)BN * ROWB;
+        for (int ks = 0; ks < nks; ++ks) {
+          bf16x8 fah[TM], fal[TM];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh, acc[i][j], 0, 0, 0);
+            const int off = abase[i] + t_off + ks * 32;
+            fah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+            fal[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int off = j * 32 * ROWB + ks * 32;
+            bf16x8 fbh = *reinterpret_cast<const bf16x8*>(bh + off);
+            bf16x8 fbl = *reinterpret_cast<const bf16x8*>(bl + off);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh, acc[i][j], 0, 0, 0);
+            }
           }
         }
+        tap_advance();
       }
     }
   };
@@ -243,7 +336,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   // (rows are visited in perm8 order, so the item range is padded to whole blocks of 8 rows)
   const int ngroups = BKH == 32 ? ((HR + 7) & ~7) * G4 : HR * G4;
   int stage_base = 0;
-  auto stage_load = [&](int c0) {
+  auto stage_load = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
       int idx = stage_base + u * NT + tid;
@@ -259,7 +352,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       stg[u] = v;
     }
   };
-  auto stage_store = [&]() {
+  auto stage_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
       int idx = stage_base + u * NT + tid;
@@ -277,10 +370,11 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 
   for (int c0 = 0; c0 < a.Cin; c0 += BKH) {
     // weight tiles of the first PF taps start flying before the halo is staged
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (u < nsteps) load_b(u, u, c0);
+    load_b(0, 0, c0);
+    load_b(1, 1, c0);
+    load_b(2, 2, c0);
     __syncthreads();   // everyone is done with the previous chunk's halo and weight buffers
+    IVF_STAMP(st_s0);
     for (stage_base = 0; stage_base < ngroups; stage_base += NSTG * NT) {
       stage_load(c0);
       stage_store();
@@ -288,21 +382,22 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     stage_base = 0;
     store_b(0, 0);
     __syncthreads();
+    IVF_STAMP(st_s1);
+    IVF_STAMP_ADD(1, st_s1, st_s0);
 
     const int cw = min(BKH, a.Cin - c0);
     const int nks = (cw + 15) >> 4;
+    t_kw = g_kw, t_kh = g_kh, t_off = g_toff;
     // tap loop unrolled by PF so the register ring is statically indexed: at tap (slot u)
     // the LDS buffer tap&1 holds its weights; slot u is refilled with tap+PF, and slot u+1's
     // weights (tap+1, loaded PF-1 taps ago) move to the other LDS buffer after the MFMAs.
-    auto tap_body = [&](auto U, int tap0) {
+    auto tap_body = [&](auto U, int tap0) __attribute__((always_inline)) {
       constexpr int u = decltype(U)::value;
-      const int tap = tap0 + u;   // step index within the chunk
-      if (tap < nsteps) {
-        if (tap + PF < nsteps) load_b(u, tap + PF, c0);
-        mma_tap(tap, tap & 1, nks);
-        if (tap + 1 < nsteps) store_b((u + 1) % PF, (tap + 1) & 1);
-        __syncthreads();
-      }
+      const int tap = tap0 + u;   // step index within the chunk (the last round may run past nsteps: no MFMAs then)
+      load_b(u, tap + PF, c0);
+      if (tap < nsteps) mma_tap(tap, tap & 1, nks);
+      store_b((u + 1) % PF, (tap + 1) & 1);
+      __syncthreads();
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
     for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
@@ -310,7 +405,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       tap_body(std::integral_constant<int, 1>{}, tap0);
       tap_body(std::integral_constant<int, 2>{}, tap0);
     }
+    IVF_STAMP(st_s2);
+    IVF_STAMP_ADD(2, st_s2, st_s1);
   }
+  IVF_STAMP(st_loop_end);
 
   if constexpr (KS == 2) {
     // meet the two tap groups: group 1 parks its partial sums in LDS (the halo is dead now),
@@ -366,6 +464,12 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         *reinterpret_cast<float4*>(a.out + ((size_t)((b * a.dT + t) * a.dH + h) * a.dW + w) * a.out_ld + a.out_coff) =
             *reinterpret_cast<const float4*>(ot + (size_t)p * 4);
     }
+    IVF_STAMP(st_end_d2s);
+    IVF_STAMP_RT(rt_end_d2s);
+    IVF_STAMP_ADD(5, rt_end_d2s, rt_begin);
+    IVF_STAMP_ADD(3, st_end_d2s, st_loop_end);
+    IVF_STAMP_ADD(0, st_end_d2s, st_begin);
+    IVF_STAMP_ADD(4, st_begin + 1, st_begin);      // workgroup count
     return;
   }
   if (wk != 0) return;
@@ -380,14 +484,35 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         return ((b * a.To + t) * a.Ho + h) * a.Wo + w;
       },
       wm * WROWS, n0 + wn * WCOLS, li, lh);
+  IVF_STAMP(st_end);
+  IVF_STAMP_RT(rt_end);
+  IVF_STAMP_ADD(5, rt_end, rt_begin);
+  IVF_STAMP_ADD(3, st_end, st_loop_end);
+  IVF_STAMP_ADD(0, st_end, st_begin);
+  IVF_STAMP_ADD(4, st_begin + 1, st_begin);        // workgroup count
 }
 
-template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH = 8, int TW = 8>
+#ifdef IVF_HALO_STAMPS
+}  // namespace ivf
+// slots: 0 total, 1 halo staging (+ first weight tile), 2 tap loops, 3 reduction + epilogue, 4 workgroups,
+// 5 total in 100 MHz s_memrealtime ticks (slot 0 / slot 5 x 100 MHz = the clock the chip held)
+extern "C" int ivf_debug_halo_stamps(unsigned long long* out8, int reset) {
+  IVF_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ivf::g_halo_stamps), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    IVF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ivf::g_halo_stamps), z, sizeof(z)));
+  }
+  return IVF_OK;
+}
+namespace ivf {
+#endif
+
+template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH = 8, int TW = 8, int TPS = 1>
 static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int NT = (TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64;
   constexpr int ROWB = (BKH + 8) * 2;
   const int HR = (TT + a.kT - 1) * halo_plane_rows<TT, TH, TW>(TH + a.kH - 1, TW + a.kW - 1);
-  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
+  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * TPS * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
   if (KS == 2 && (size_t)TT * TH * TW * BN * 4 > (size_t)2 * HR * ROWB) {
     set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
     return IVF_ERR_UNSUPPORTED;
@@ -398,7 +523,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW>),
+    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -406,10 +531,10 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   a.ntiles = cdiv(a.Cout, BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
-  prof_name(IVF_CONV_HALO_BASE + variant_id, "conv3d_halo_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", TT, BN, WROWS, WCOLS, KS, BKH,
-            TH, TW);
+  prof_name(IVF_CONV_HALO_BASE + variant_id, "conv3d_halo_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", TT, BN, WROWS, WCOLS, KS,
+            BKH, TH, TW, TPS);
   const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
-  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
+  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -439,7 +564,11 @@ int conv_halo_supported(const ConvKArgs& a) {
 // and LDS round trip hide under another's MFMAs -- what the 32-column stem backward-data is short of):
 // 31: 2 32 64 x 32 2    32: 2 32 32 x 32 2    33: 2 32 32 x 32 1    34: 2 64 32 x 64 2    35: 2 64 64 x 64 2
 // 36: 4 32 64 x 32 2 (16)   37: 4 32 32 x 32 2 (16)
-int conv_halo_num_variants() { return 38; }
+// several taps per barrier interval (narrow outputs; 16-channel chunks leave the LDS room):
+// 38: 4 32 32 x 32 2 (16) x4 taps   39: 4 32 64 x 32 2 (16) x4   40: 4 32 32 x 32 2 (16) x2   41: 2 32 32 x 32 2 (32) x2
+// 42: 4 64 32 x 64 1 (16) x2        43: 4 64 32 x 64 1 (32) x2   44: 4 32 32 x 32 1 (16) x4   45: 4 96 32 x 96 1 (16) x2
+// 46: 4 32 32 x 32 2 (32) x2 (k <= 3)   47: 4x4x14 box, 64 32 x 64 1 (32) x2
+int conv_halo_num_variants() { return 48; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -481,6 +610,16 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 35: return launch_halo<2, 64, 64, 64, 2, 16>(a, 35, s);
     case 36: return launch_halo<4, 32, 64, 32, 2, 16>(a, 36, s);
     case 37: return launch_halo<4, 32, 32, 32, 2, 16>(a, 37, s);
+    case 38: return launch_halo<4, 32, 32, 32, 2, 16, 8, 8, 4>(a, 38, s);
+    case 39: return launch_halo<4, 32, 64, 32, 2, 16, 8, 8, 4>(a, 39, s);
+    case 40: return launch_halo<4, 32, 32, 32, 2, 16, 8, 8, 2>(a, 40, s);
+    case 41: return launch_halo<2, 32, 32, 32, 2, 32, 8, 8, 2>(a, 41, s);
+    case 42: return launch_halo<4, 64, 32, 64, 1, 16, 8, 8, 2>(a, 42, s);
+    case 43: return launch_halo<4, 64, 32, 64, 1, 32, 8, 8, 2>(a, 43, s);
+    case 44: return launch_halo<4, 32, 32, 32, 1, 16, 8, 8, 4>(a, 44, s);
+    case 45: return launch_halo<4, 96, 32, 96, 1, 16, 8, 8, 2>(a, 45, s);
+    case 46: return launch_halo<4, 32, 32, 32, 2, 32, 8, 8, 2>(a, 46, s);
+    case 47: return launch_halo<4, 64, 32, 64, 1, 32, 4, 14, 2>(a, 47, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

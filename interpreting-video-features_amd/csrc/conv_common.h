@@ -5,6 +5,7 @@
 namespace ivf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;

@@ -36,7 +36,7 @@ def gather_records(records, clip_id_col=0, equal_shards=False):
     shard with clip id -1 and dropped afterwards (two collectives)."""
     if records.dtype != torch.int32:
         raise TypeError("records must be int32 rows (ivf_search.pack_records)")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return _sort_rows(records, clip_id_col)
     world = dist.get_world_size()
     R = records.shape[1]
