@@ -14,6 +14,10 @@
 
 #include "conv_common.h"
 
+#ifndef IVF_ABLATE
+#define IVF_ABLATE 0   // timing ablations of the tap loop (diagnostic builds only; results are wrong when != 0)
+#endif
+
 namespace ivf {
 
 // Diagnostic build only (make stamps -> libivf_hip_stamps.so, tools/halo_stamps.py): thread 0 of every
@@ -108,6 +112,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
                                                                                                 int tilesW) {
   constexpr int BM = TT * TH * TW;
   static_assert(BM % WROWS == 0 && WROWS % 32 == 0 && BN % WCOLS == 0 && WCOLS % 32 == 0, "tile");
+  static_assert((KS * BN * (BKH / 8)) % 64 == 0, "weight-stream slots must fill whole waves");
   constexpr int WM = BM / WROWS, WN = BN / WCOLS;
   constexpr int NT = WM * WN * KS * 64;
   constexpr int TM = WROWS / 32, TN = WCOLS / 32;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   // a double-buffered LDS tile.
   constexpr int PF = 3;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 rbh[PF][BLOADS], rbl[PF][BLOADS];
+  u32x4 rbh[PF][BLOADS] = {}, rbl[PF][BLOADS] = {};
   // Per-thread constants of the weight stream, decoded once: the tap loop only adds the tap and the chunk.  (The
   // scalar unit is what a narrow tile runs out of: 75 scalar + 28 vector instructions per tap beside 6 MFMAs
   // measured 53 % scalar-busy at 36 % MFMA-busy on the stem's backward-data.)
@@ -211,6 +216,11 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     b_tap[q] = sub < TPS ? sub + grp * ntg : 0;
     b_c[q] = 8 * g2;
   }
+  // Kept straight-line on purpose: no scalar branch around the loads or the stores (lanes without a slot are
+  // masked off, which is not a branch for a block this short), and the loop below issues them every step.  Then
+  // the compiler can count (`s_waitcnt vmcnt(4)` before a slot is stored); behind any control-flow join it falls
+  // back to vmcnt(0) right after issuing the prefetch.  (Hand-issued asm loads were tried: the compiler copies
+  // asm outputs between registers while the load is still in flight.)
   auto load_b = [&](int slot, int step, int c0) __attribute__((always_inline)) {
     const int s0 = min(step, nsteps - 1) * TPS;
 #pragma unroll
@@ -219,8 +229,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       int c = c0 + b_c[q];
       c = c < a.Cin ? c : 0;
       const unsigned short* p = a.wbf + (size_t)(b_src[q] + tap * a.Cin + c);
-      rbh[slot][q] = *reinterpret_cast<const u32x4*>(p);
-      rbl[slot][q] = *reinterpret_cast<const u32x4*>(p + a.w_lo_off);
+      if (b_dst[q] >= 0) {
+        rbh[slot][q] = *reinterpret_cast<const u32x4*>(p);
+        rbl[slot][q] = *reinterpret_cast<const u32x4*>(p + a.w_lo_off);
+      }
     }
   };
   auto store_b = [&](int slot, int buf) __attribute__((always_inline)) {
@@ -286,7 +298,9 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         if (u / NKS < nsub) {
           if (u + 1 < TPS * NKS && (u + 1) / NKS < nsub) {
             if ((u + 1) % NKS == 0) tap_advance();
+#if IVF_ABLATE != 3 && IVF_ABLATE != 4
             issue((u + 1) & 1, (u + 1) / NKS, (u + 1) % NKS);
+#endif
           }
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[u & 1], fbh[u & 1], acc[0][0], 0, 0, 0);
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[u & 1], fbl[u & 1], acc[0][0], 0, 0, 0);
@@ -380,6 +394,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       stage_store();
     }
     stage_base = 0;
+    // everything the compiler knows to be in flight has landed by now; saying so keeps its conservative
+    // `s_waitcnt vmcnt(0)` (staging registers reused by the fragment reads) out of the tap loop, where it would
+    // drain the weight prefetch every step
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     store_b(0, 0);
     __syncthreads();
     IVF_STAMP(st_s1);
@@ -394,10 +412,16 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     auto tap_body = [&](auto U, int tap0) __attribute__((always_inline)) {
       constexpr int u = decltype(U)::value;
       const int tap = tap0 + u;   // step index within the chunk (the last round may run past nsteps: no MFMAs then)
+#if IVF_ABLATE != 2
       load_b(u, tap + PF, c0);
+#endif
       if (tap < nsteps) mma_tap(tap, tap & 1, nks);
+#if IVF_ABLATE != 2
       store_b((u + 1) % PF, (tap + 1) & 1);
+#endif
+#if IVF_ABLATE != 1 && IVF_ABLATE != 4
       __syncthreads();
+#endif
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
     for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
