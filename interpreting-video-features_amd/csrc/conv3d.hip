@@ -172,7 +172,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
 // product exact in fp32, fp32 accumulation in the MFMA.  3 x v_mfma_f32_32x32x16_bf16 per 16-deep
 // k-step = 96 cycles against 512 for the fp32 MFMA form.  Activations stay fp32 in HBM and are
 // split while they are staged into LDS; weights are pre-split by the pack kernels.
-template <int BM, int BN, int WM, int WN>
+// PW = pointwise (1x1x1, stride 1, no padding: every 1x1x1 unit of the Inception modules and their fused
+// backward GEMM): A is a plain [M][K] matrix, so the per-chunk tap decode (three integer divisions and the bounds
+// tests per thread: 12-41 vector instructions per MFMA, measured) drops out; rows are addressed through two
+// pointers computed once, loads are unconditional (rows past M and the k tail are clamped: they meet zero weights
+// or land in rows nobody stores).
+template <int BM, int BN, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -203,10 +208,17 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   const int q0 = perm8(tid >> 2);   //    rows q0 + 64 j
 
   int a_base[AROWS], a_t0[AROWS], a_h0[AROWS], a_w0[AROWS];
+  const float* a_p1[AROWS];
+  const float* a_p2[AROWS];
 #pragma unroll
   for (int j = 0; j < AROWS; ++j) {
     int m = m0 + r0 + 32 * j;
-    if (m < a.M) {
+    if constexpr (PW) {
+      const size_t mc = (size_t)min(m, a.M - 1);
+      a_p1[j] = a.in + mc * a.in_ld + a.in_coff;
+      a_p2[j] = a.in2 ? a.in2 + mc * a.in2_ld + a.in2_coff - a.K0 : a_p1[j];
+      a_base[j] = a_t0[j] = a_h0[j] = a_w0[j] = 0;
+    } else if (m < a.M) {
       int wo = m % a.Wo;
       int t1 = m / a.Wo;
       int ho = t1 % a.Ho;
@@ -233,27 +245,34 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   const int khw = a.kH * a.kW;
 
   auto load_chunk = [&](int k0) {
-    int kk = k0 + 4 * g;
-    bool kvalid = kk < a.K;
-    int tap = kvalid ? kk / a.Cin : 0;
-    int ci = kk - tap * a.Cin;
-    int kt = tap / khw;
-    int rem = tap - kt * khw;
-    int kh = rem / a.kW;
-    int kw = rem - kh * a.kW;
+    if constexpr (PW) {
+      const int kk = min(k0 + 4 * g, a.K - 4);
+      const bool second = a.in2 && kk >= a.K0;
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) {
-      int ti = a_t0[j] + kt, hi = a_h0[j] + kh, wi = a_w0[j] + kw;
-      bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
-                (unsigned)wi < (unsigned)a.Wi;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
-        v = (a.in2 && kk >= a.K0)
-                ? *reinterpret_cast<const float4*>(a.in2 + pos * a.in2_ld + a.in2_coff + (kk - a.K0))
-                : *reinterpret_cast<const float4*>(a.in + pos * a.in_ld + a.in_coff + ci);
+      for (int j = 0; j < AROWS; ++j) ra[j] = *reinterpret_cast<const float4*>((second ? a_p2[j] : a_p1[j]) + kk);
+    } else {
+      int kk = k0 + 4 * g;
+      bool kvalid = kk < a.K;
+      int tap = kvalid ? kk / a.Cin : 0;
+      int ci = kk - tap * a.Cin;
+      int kt = tap / khw;
+      int rem = tap - kt * khw;
+      int kh = rem / a.kW;
+      int kw = rem - kh * a.kW;
+#pragma unroll
+      for (int j = 0; j < AROWS; ++j) {
+        int ti = a_t0[j] + kt, hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+        bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
+                  (unsigned)wi < (unsigned)a.Wi;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
+          v = (a.in2 && kk >= a.K0)
+                  ? *reinterpret_cast<const float4*>(a.in2 + pos * a.in2_ld + a.in2_coff + (kk - a.K0))
+                  : *reinterpret_cast<const float4*>(a.in + pos * a.in_ld + a.in_coff + ci);
+        }
+        ra[j] = v;
       }
-      ra[j] = v;
     }
     int kb = k0 + 8 * g2;
 #pragma unroll
@@ -471,13 +490,21 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
     }
   }
   prof_name(cls, "%s<%d,%d,%d,%d>", math ? "conv3d_igemm_bf16x3_kernel" : "conv3d_igemm_kernel", BM, BN, WM, WN);
+  // a plain GEMM over the pixels: no taps, no strides, no padding
+  const bool pw = a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 && a.pW == 0 &&
+                  a.To == a.Ti && a.Ho == a.Hi && a.Wo == a.Wi && a.K >= 4 && a.K % 4 == 0 && !a.d2s;
   const bool timed = prof_begin(s, cls);
   if constexpr (BN > 128 || BM == 64) {
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    if (pw)
+      hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
   } else if (math == 0)
     hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  else if (pw)
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
