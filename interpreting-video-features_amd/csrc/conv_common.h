@@ -39,14 +39,6 @@ struct ConvKArgs {
   int in2_ld, in2_coff, K0;
 };
 
-__device__ __forceinline__ int xcd_remap(int id, int nwg) {
-  // Blocks are dealt round-robin over 8 XCDs; give each XCD a contiguous range of
-  // tiles so blocks sharing an A panel share an L2 (bijective form).
-  int q = nwg >> 3, r = nwg & 7;
-  int xcd = id & 7, pos = id >> 3;
-  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + pos;
-}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDS_ROW_BF = BK + 8;  // bf16 per LDS row: 80 B rows make the ds_read_b128 fragment reads conflict-free

@@ -61,4 +61,15 @@ static inline int same_out(int n, int k, int s) {
   return (n + f + b - k) / s + 1;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): hand every XCD a contiguous range of
+// tiles, so that tiles sharing input rows share an L2 (bijective on [0, nwg)).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  // Blocks are dealt round-robin over 8 XCDs; give each XCD a contiguous range of
+  // tiles so blocks sharing an A panel share an L2 (bijective form).
+  int q = nwg >> 3, r = nwg & 7;
+  int xcd = id & 7, pos = id >> 3;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
+
 }  // namespace ivf

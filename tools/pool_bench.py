@@ -1,7 +1,9 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
-import torch, ivf_lib as L
+import ivf_lib as L
+if os.environ.get("IVF_DIAG_LIB"): L.LIB_PATH = os.path.join(ROOT, "interpreting-video-features_amd", os.environ["IVF_DIAG_LIB"])
+import torch
 lib = L.lib()
 cases = {'3c.b3a': (64, 8, 28, 28, 480, (3,3,3), (1,1,1)), '2a': (64, 8, 112, 112, 64, (1,3,3), (1,2,2)), '3a': (64, 8, 56, 56, 192, (1,3,3), (1,2,2)), '4a': (64, 8, 28, 28, 480, (3,3,3), (2,2,2)),
          '4f.b3a': (64, 4, 14, 14, 528, (3,3,3), (1,1,1))}
