@@ -65,6 +65,10 @@ struct Op {
   double flops_per_clip = 0.0;  // algorithmic: 2 * out positions * Cout * taps * REAL Cin (same for bwd-data)
   // backward bookkeeping for grad(src)
   bool bwd_accumulate = false, bwd_mask = false;
+  // Inception module this op belongs to (-1: trunk) and whether it runs on the side stream: the HBM-bound branch
+  // (b0 forward; the 3x3x3 pool and b3b both ways) overlaps the MFMA-bound 3x3x3 convs of the other branches
+  int module = -1;
+  bool side_fwd = false, side_bwd = false;
 };
 
 }  // namespace ivf
@@ -86,6 +90,14 @@ struct ivf_i3d {
   float* warena = nullptr;
   char* ws = nullptr;
   std::vector<bool> loaded;
+  // side stream + fork/join events (created on first use: the plan itself is built without a GPU)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Off by default: measured +0.7 % clips/s at B = 64.  The branch it hides is HBM-bound and needs about half the
+  // CUs to hold its bandwidth (~24 GB/s per CU), while a 3x3x3 conv workgroup needs a CU to itself (all of its LDS
+  // and registers), so the two mostly trade CUs instead of sharing them (b1b of Mixed_3b: 706 -> 1005 us while
+  // 600 us of side work ran beside it).
+  bool overlap = false;
 
   float* act(int i) const { return (float*)ws + bufs[i].act_off; }
   float* grad(int i) const { return (float*)ws + bufs[i].grad_off; }
@@ -208,7 +220,9 @@ static int build_plan(ivf_i3d* n) {
       A.fus_owner = l0; A.fus_koff = t[1]; A.fus_ktotal = kt;
       Bq.fus_owner = l0; Bq.fus_koff = t[1] + t[2]; Bq.fus_ktotal = kt;
     }
+    const size_t first_op = n->ops.size();
     b.conv_op(l0, x, 0, y, 0);
+    n->ops.back().side_fwd = true;
     n->ops.back().bwd_fused = true;
     n->ops.back().src2 = t12;
     n->ops.back().flops_bwd_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[1] + t[2] + t[4]);
@@ -221,7 +235,10 @@ static int build_plan(ivf_i3d* n) {
     b.conv_op(l1b, t12, 0, y, t[1]);
     b.conv_op(l2b, t12, t[2], y, t[1] + t[3]);
     b.pool_op(x, t3, 3, 3, 3, 1, 1, 1);
+    n->ops.back().side_fwd = n->ops.back().side_bwd = true;
     b.conv_op(l3b, t3, 0, y, t[1] + t[3] + t[5]);
+    n->ops.back().side_fwd = n->ops.back().side_bwd = true;
+    for (size_t i = first_op; i < n->ops.size(); ++i) n->ops[i].module = m;
     x = y;
   }
   n->feat_buf = x;
@@ -414,26 +431,75 @@ static int check_ready(const ivf_i3d* n, int b) {
   return IVF_OK;
 }
 
+// Fork/join of the side stream around the ops of one Inception module.  Every buffer of the plan has its own
+// storage, so the only orderings to keep are the true dependencies: the side branch reads the module input (fork
+// after everything before it on the caller's stream), the next consumer of the module output -- or of grad(input),
+// which the pool's backward writes first and the fused 1x1x1 backward GEMM accumulates into -- waits for it (join).
+struct SideLane {
+  ivf_i3d* n;
+  hipStream_t main;
+  bool enabled, forked = false;
+  int rc = IVF_OK;
+  SideLane(ivf_i3d* net, hipStream_t s) : n(net), main(s) {
+    enabled = net->overlap;
+    if (enabled && !n->side) {
+      if (hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("i3d: could not create the side stream");
+        rc = IVF_ERR_HIP;
+        enabled = false;
+      }
+    }
+  }
+  hipStream_t side() {   // stream for a side-lane op (forks on first use inside a module)
+    if (!enabled) return main;
+    if (!forked) {
+      if (hipEventRecord(n->ev_fork, main) != hipSuccess || hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) rc = IVF_ERR_HIP;
+      forked = true;
+    }
+    return n->side;
+  }
+  void join() {
+    if (!forked) return;
+    if (hipEventRecord(n->ev_join, n->side) != hipSuccess || hipStreamWaitEvent(main, n->ev_join, 0) != hipSuccess) rc = IVF_ERR_HIP;
+    forked = false;
+  }
+};
+
 static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream_t s) {
+  SideLane lane(n, s);
+  IVF_PROPAGATE(lane.rc);
+  int module = -1;
   for (const Op& o : n->ops) {
+    if (o.module != module) {   // the module input must be complete: wait for the previous module's side branch
+      lane.join();
+      module = o.module;
+    }
+    hipStream_t st = o.side_fwd ? lane.side() : s;
     prof_set_site(o.type == Op::CONV ? 2 * (int)(&o - n->ops.data()) : -1);
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_fwd(n, o, b, &d);
       prof_set_flops(o.flops_per_clip * b);
+      int rc;
       if (o.fwd_group)
-        IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.grp_wf_off, n->warena + L.grp_scale_off,
-                                 n->warena + L.grp_shift_off, nullptr, n->act(o.dst), s));
+        rc = ivf_conv3d(&d, n->act(o.src), n->warena + L.grp_wf_off, n->warena + L.grp_scale_off,
+                        n->warena + L.grp_shift_off, nullptr, n->act(o.dst), st);
       else
-        IVF_PROPAGATE(ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off,
-                                 n->warena + L.shift_off, nullptr, n->act(o.dst), s));
+        rc = ivf_conv3d(&d, n->act(o.src), n->warena + L.wf_off, n->warena + L.scale_off, n->warena + L.shift_off,
+                        nullptr, n->act(o.dst), st);
+      if (rc != IVF_OK) { lane.join(); return rc; }
     } else {
       ivf_pool3d_desc d;
       fill_pool(n, o, b, &d);
-      IVF_PROPAGATE(ivf_maxpool3d_fwd(&d, n->act(o.src), n->act(o.dst), n->at<unsigned char>(o.idx_off), s));
+      int rc = ivf_maxpool3d_fwd(&d, n->act(o.src), n->act(o.dst), n->at<unsigned char>(o.idx_off), st);
+      if (rc != IVF_OK) { lane.join(); return rc; }
     }
   }
+  lane.join();
+  IVF_PROPAGATE(lane.rc);
   const ActBuf& f = n->bufs[n->feat_buf];
   const ConvLayer& L = n->convs.back();
   float* lg = n->at<float>(n->off_logits);
@@ -455,28 +521,42 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
   IVF_PROPAGATE(ivf_head_bwd(n->act(n->feat_buf), n->warena + Lh.wf_off, n->at<float>(n->off_probs), target,
                              dout, score, nullptr, n->grad(n->feat_buf), b, f.T * f.H * f.W, f.C,
                              n->cfg.num_classes, n->cfg.softmax, 1, s));
+  SideLane lane(n, s);
+  IVF_PROPAGATE(lane.rc);
+  int module = -1;
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     const Op& o = n->ops[i];
+    if (o.module != module) {   // grad(module output) must be complete
+      lane.join();
+      module = o.module;
+    }
     if (n->cam_buf >= 0 && o.dst == n->cam_buf) break;   // Grad-CAM pass: the target's gradient is complete
     if (o.bwd_skip) continue;
+    // the fused 1x1x1 backward GEMM accumulates into grad(input) after the pool's backward has written it
+    if (o.bwd_fused) lane.join();
+    hipStream_t st = o.side_bwd ? lane.side() : s;
     const float* gate = (o.bwd_mask && o.src != n->cam_buf) ? n->act(o.src) : nullptr;
     prof_set_site(o.type == Op::CONV ? 2 * i + 1 : -1);
+    int rc;
     if (o.type == Op::CONV) {
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_bwd(n, o, b, &d);
       prof_set_flops((o.bwd_fused ? o.flops_bwd_per_clip : o.flops_per_clip) * b);
-      IVF_PROPAGATE(ivf_conv3d(&d, n->grad(o.dst), n->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr,
-                               nullptr, gate, n->grad(o.src), s));
+      rc = ivf_conv3d(&d, n->grad(o.dst), n->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr, nullptr, gate,
+                      n->grad(o.src), st);
     } else {
       ivf_pool3d_desc d;
       fill_pool(n, o, b, &d);
       // sole writer of a ReLU output's gradient: gated through the arg-max record (fill_pool);
       // with other writers before it the accumulated sum still needs the explicit gate
-      IVF_PROPAGATE(ivf_maxpool3d_bwd(&d, n->grad(o.dst), n->at<unsigned char>(o.idx_off), n->grad(o.src),
-                                      o.bwd_accumulate ? gate : nullptr, o.bwd_accumulate, s));
+      rc = ivf_maxpool3d_bwd(&d, n->grad(o.dst), n->at<unsigned char>(o.idx_off), n->grad(o.src),
+                             o.bwd_accumulate ? gate : nullptr, o.bwd_accumulate, st);
     }
+    if (rc != IVF_OK) { lane.join(); return rc; }
   }
+  lane.join();
+  IVF_PROPAGATE(lane.rc);
   return IVF_OK;
 }
 
@@ -525,6 +605,7 @@ extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
   IVF_CHECK_ARG(cfg->math == IVF_MATH_FP32 || cfg->math == IVF_MATH_BF16X3, "i3d_create: unknown math mode");
   ivf_i3d* n = new ivf_i3d();
   n->cfg = *cfg;
+  n->overlap = getenv("IVF_OVERLAP") != nullptr && getenv("IVF_OVERLAP")[0] == '1';
   int rc = build_plan(n);
   if (rc != IVF_OK) {
     delete n;
@@ -534,7 +615,19 @@ extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
   return IVF_OK;
 }
 
-extern "C" void ivf_i3d_destroy(ivf_i3d_t* net) { delete net; }
+extern "C" int ivf_i3d_set_overlap(ivf_i3d_t* net, int on) {
+  IVF_CHECK_ARG(net, "i3d_set_overlap: null net");
+  net->overlap = on != 0;
+  return IVF_OK;
+}
+
+extern "C" void ivf_i3d_destroy(ivf_i3d_t* net) {
+  if (!net) return;
+  if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+  if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+  if (net->side) (void)hipStreamDestroy(net->side);
+  delete net;
+}
 extern "C" size_t ivf_i3d_weights_bytes(const ivf_i3d_t* net) { return net ? net->weights_floats * 4 : 0; }
 extern "C" size_t ivf_i3d_workspace_bytes(const ivf_i3d_t* net) { return net ? net->ws_bytes : 0; }
 

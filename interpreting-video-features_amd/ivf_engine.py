@@ -125,6 +125,11 @@ class I3DEngine:
             torch.cuda.current_stream().synchronize()
         self._tuned = True
 
+    def set_overlap(self, on):
+        """Run the HBM-bound branch of every Inception module on a side stream beside the 3x3x3 convs
+        (ivf_i3d_set_overlap; off by default, bit-identical results)."""
+        L.check(L.lib().ivf_i3d_set_overlap(self._h, int(bool(on))))
+
     def get_tuning(self):
         n = 2 * L.lib().ivf_i3d_num_conv_ops(self._h)
         arr = (c_int * n)()

@@ -91,6 +91,7 @@ _SIGS = {
     "ivf_argmax": (c_int, [_P, _I, _I, _P, _P]),
     "ivf_i3d_create": (c_int, [POINTER(I3DConfig), POINTER(c_void_p)]),
     "ivf_i3d_destroy": (None, [_P]),
+    "ivf_i3d_set_overlap": (_I, [_P, _I]),
     "ivf_i3d_weights_bytes": (c_size_t, [_P]),
     "ivf_i3d_workspace_bytes": (c_size_t, [_P]),
     "ivf_i3d_bind": (c_int, [_P, _P, _P]),

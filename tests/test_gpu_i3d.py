@@ -207,6 +207,24 @@ def test_batch_rows_independent(s16):
     assert torch.equal(pab[1], pa[0])
 
 
+def test_side_stream_overlap_is_bit_identical(s16):
+    """ivf_i3d_set_overlap: the pool / b0 / b3b branch of every Inception module on a side stream (fork/join per
+    module) must not change a bit of the probabilities, the scores or the input gradient."""
+    import ivf_recipe as R
+    x = torch.from_numpy(np.stack([R.clip(7), R.clip(8)])).cuda()
+    tgt = torch.tensor([3, 11], dtype=torch.int32)
+    out = []
+    for on in (False, True, True):
+        s16.set_overlap(on)
+        probs = s16.forward(x).clone()
+        score, dx = s16.backward(2, target=tgt)
+        out.append((probs, score.clone(), dx.clone()))
+    s16.set_overlap(False)
+    for k in (1, 2):
+        for a, b in zip(out[0], out[k]):
+            assert torch.equal(a, b)
+
+
 def test_gradcam_vs_reference(s16, golden):
     import ivf_recipe as R
     g = golden('gradcam')
