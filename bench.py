@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32_exact and convlstm blocks")
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
+    ap.add_argument("--tuning", default=None,
+                    help="JSON file with a per-layer kernel choice: loaded instead of autotuning when it exists and fits "
+                         "this plan, written after autotuning otherwise (profiling runs: no tuner launches in the trace)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default=None,
                     help="arithmetic of the Unit3D convolutions (default: ivf_engine.DEFAULT_MATH)")
     return ap.parse_args()
@@ -228,7 +231,7 @@ def collect_roofline(L, eng, B):
     }
 
 
-def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, lam1, lam2):
+def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, lam1, lam2, tuning_file=None):
     """W untimed + K timed steps of the full I3D search.  Returns (elapsed_s, roofline, engine math)."""
     import ivf_engine
     import ivf_lib as L
@@ -237,7 +240,26 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
     import ivf_shard
     eng = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=B, softmax=True,
                                stride_mod_layers="" if T == 16 else "none", device=dev, math=math)
-    eng.load_state_dict(R.i3d_state_dict(num_classes=174), autotune=(rank == 0))
+    saved = None
+    if tuning_file and os.path.exists(tuning_file):
+        try:
+            doc = json.load(open(tuning_file))
+            if doc.get("batch") == B and doc.get("math") == eng.math and doc.get("frames") == T:
+                saved = doc["variants"]
+        except (OSError, ValueError, KeyError):
+            saved = None
+    eng.load_state_dict(R.i3d_state_dict(num_classes=174), autotune=(rank == 0 and saved is None))
+    if saved is not None:
+        try:
+            eng.set_tuning(saved)
+        except L.IvfError:
+            eng.autotune()
+            saved = None
+    if tuning_file and saved is None and rank == 0:
+        try:
+            json.dump({"batch": B, "math": eng.math, "frames": T, "variants": eng.get_tuning()}, open(tuning_file, "w"))
+        except OSError:
+            pass
     if dist is not None:
         # every rank must run the SAME kernel variant per layer (bit-identical per-clip results):
         # rank 0 tunes, one small broadcast installs its choice everywhere
@@ -355,7 +377,7 @@ def main():
     lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
     T, B = args.frames, args.batch
     elapsed, roofline, math = timed_i3d(torch, dist, dev, rank, world, args.math, B, T, args.iters, args.steps,
-                                        args.warmup, lam1, lam2)
+                                        args.warmup, lam1, lam2, tuning_file=args.tuning)
     if rank == 0:
         clips = world * B * args.steps
         out = {

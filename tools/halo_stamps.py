@@ -78,4 +78,4 @@ if not ONLY:
   run("Mixed_3c.b1b fwd", 128, 192, 3, (8, 28, 28), [16, 39, 40])
   run("Mixed_4f.b1b fwd", 160, 320, 3, (4, 14, 14), [16, 18])
   run("Mixed_3b.b2b fwd", 16, 32, 3, (8, 28, 28), [37, 62, 58, 59, 63])
-run("stem bwd", 0, 0, 0, None, [33] if ONLY else [33, 23, 54, 55, 56, 57, 60], bwd_d2s=True)
+run("stem bwd", 0, 0, 0, None, [33, 23, 55] if ONLY else [33, 23, 54, 55, 56, 57, 60], bwd_d2s=True)
