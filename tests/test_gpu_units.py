@@ -297,6 +297,59 @@ def test_every_conv_variant_matches_torch(k, cin, cout, thw):
     assert ran >= 3
 
 
+@pytest.mark.parametrize("k0,k1,cout,thw,math", [(40, 24, 72, (3, 7, 9), "bf16x3"), (96, 16, 200, (2, 5, 11), "bf16x3"),
+                                                 (32, 8, 48, (1, 9, 7), "bf16x3"), (40, 24, 72, (3, 7, 9), "fp32")])
+def test_pointwise_conv_two_sources(k0, k1, cout, thw, math):
+    """The pointwise (1x1x1) path of the implicit GEMM with its second input (ivf_conv3d_desc.in2 / K0: one
+    backward GEMM over gradients living in two buffers): K0 off the 32-wide chunk grid, a k tail, row counts off the
+    tile grid, sources with row lengths / channel offsets of their own, every tile variant, with the
+    accumulate + ReLU-gate epilogue -- against torch fp64 on the concatenated input."""
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(11)
+    B = 2
+    K = k0 + k1
+    x1 = torch.randn((B,) + thw + (k0 + 8,), generator=gen)     # channels [4, 4 + k0) are the first source
+    x2 = torch.randn((B,) + thw + (k1 + 12,), generator=gen)    # channels [8, 8 + k1) the second
+    w = torch.randn(cout, K, 1, 1, 1, generator=gen) * 0.1
+    xin = torch.cat([x1[..., 4:4 + k0], x2[..., 8:8 + k1]], dim=-1).double()
+    ref = torch.einsum('bthwk,nk->bthwn', xin, w.view(cout, K).double())
+    mm = L.MATH_MODES[math]
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, K, 1, 1, 1, mm), device='cuda')
+    wd = w.cuda()
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, K, K, 1, 1, 1, mm, L.stream()))
+    x1d, x2d = x1.cuda(), x2.cuda()
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = K, k0 + 8, 4
+    d.K0, d.in2_ld, d.in2_coff, d.in2 = k0, k1 + 12, 8, x2d.data_ptr()
+    d.To, d.Ho, d.Wo = thw
+    d.Cout, d.out_ld, d.out_coff = cout, cout + 4, 4
+    d.kT = d.kH = d.kW = 1
+    d.sT = d.sH = d.sW = 1
+    d.math = mm
+    d.mask_ld, d.mask_coff = cout, 0
+    ids = (ctypes.c_int * 64)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    base = torch.randn((B,) + thw + (cout + 4,), generator=gen)
+    gate = (torch.rand((B,) + thw + (cout,), generator=gen) > 0.3).float()
+    want = (base[..., 4:].double() + ref) * gate.double()
+    gated, ran = gate.cuda(), 0
+    tol = 1e-4 if math == "bf16x3" else 1e-5
+    for v in list(ids)[:n]:
+        d.variant = v
+        d.relu, d.accumulate = 0, 1
+        acc = base.clone().cuda()
+        rc = lib.ivf_conv3d(ctypes.byref(d), L.ptr(x1d), L.ptr(wf), None, None, L.ptr(gated), L.ptr(acc), L.stream())
+        if rc != 0:
+            continue
+        ran += 1
+        got = acc.cpu()
+        assert torch.equal(got[..., :4], base[..., :4]), f"variant {v} wrote outside its channel window"
+        assert rel_err(got[..., 4:].double().numpy(), want.numpy()) < tol, f"variant {v}"
+    assert ran >= 3
+
+
 @pytest.mark.parametrize("k,st,thw", [((1, 3, 3), (1, 2, 2), (3, 17, 20)), ((3, 3, 3), (2, 2, 2), (5, 15, 14)),
                                       ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 2, 2), (4, 15, 9)),
                                       ((2, 2, 2), (1, 2, 2), (4, 8, 7)), ((2, 2, 2), (2, 2, 2), (3, 7, 7))])
