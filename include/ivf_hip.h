@@ -147,6 +147,12 @@ typedef struct {
    * positions; row length in2_ld, channel offset in2_coff), channels [0, K0) from `in` */
   int K0, in2_ld, in2_coff;
   const float* in2;
+  /* optional second OUTPUT window (forward epilogues only: no accumulate, no relu_mask, no d2s): columns
+   * [N0, Cout) are written to out2 (row length out2_ld, channel offset out2_coff, column n - N0) instead of
+   * `out` -- one GEMM for several units that read the same input and write different buffers (an Inception
+   * module's b0 | b1a | b2a).  Served by the implicit-GEMM tiles only. */
+  int N0, out2_ld, out2_coff;
+  float* out2;
 } ivf_conv3d_desc;
 
 /* Kernel variants: tile shapes of the plain implicit GEMM (IVF_CONV_IGEMM_BASE + 0..2) and of

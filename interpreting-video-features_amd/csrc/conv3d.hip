@@ -596,6 +596,16 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
                       d->in2_coff + (d->Cin - d->K0) <= d->in2_ld,
                   "conv3d: second-input channel window must be 4-aligned inside its row");
   }
+  a.out2 = d->out2; a.out2_ld = d->out2_ld; a.out2_coff = d->out2_coff; a.N0 = d->N0;
+  if (d->out2) {
+    IVF_CHECK_ARG(!d->accumulate && relu_mask == nullptr && !d->d2s,
+                  "conv3d: a second output window is a forward-epilogue feature (no accumulate / relu_mask / d2s)");
+    IVF_CHECK_ARG(d->N0 > 0 && d->N0 < d->Cout && d->out2_coff >= 0 && d->out2_coff + (d->Cout - d->N0) <= d->out2_ld &&
+                      d->out_coff + d->N0 <= d->out_ld,
+                  "conv3d: output windows [0,N0) / [N0,Cout) must fit their rows");
+    IVF_CHECK_ARG(d->variant == IVF_CONV_AUTO || (d->variant >= IVF_CONV_IGEMM_BASE && d->variant < IVF_CONV_PIX4),
+                  "conv3d: a second output window is served by the implicit-GEMM tiles only");
+  }
   IVF_CHECK_ARG(d->math == 0 || d->math == 1, "conv3d: math must be 0 (fp32 MFMA) or 1 (split-bf16 x3)");
   a.ldw = pack_ldw(a.K, d->math);
   a.wbf = reinterpret_cast<const unsigned short*>(w_packed);
@@ -611,7 +621,7 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     IVF_CHECK_ARG(d->dT > 0 && d->dH > 0 && d->dW > 0 && d->dC > 0 && d->dC <= d->Cout / 8,
                   "conv3d: bad depth-to-space dims");
     IVF_CHECK_ARG(d->out_coff + d->dC <= d->out_ld, "conv3d: d2s output window outside ld");
-  } else {
+  } else if (!d->out2) {
     IVF_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld, "conv3d: output window outside ld");
   }
   if (d->math == 0) IVF_CHECK_ARG(a.ldw == a.K, "conv3d: internal ldw");
@@ -628,8 +638,8 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     }
     return conv_igemm_launch_variant(a, d->math, d->variant - IVF_CONV_IGEMM_BASE, (hipStream_t)stream);
   }
-  if (d->math == 1 && !no_halo && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
-  if (d->math == 1 && !no_halo && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
+  if (d->math == 1 && !no_halo && !d->out2 && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
+  if (d->math == 1 && !no_halo && !d->out2 && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
 
@@ -727,6 +737,7 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   ConvKArgs a{};
   a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
   a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.d2s = d->d2s; a.in2 = d->in2;
+  if (d->out2) return n;   // second output window: implicit-GEMM tiles only
   if (d->math == 1 && conv_halo_supported(a))
     for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
   if (d->math == 1 && conv_pix4_supported(a) && n < max_ids) ids[n++] = IVF_CONV_PIX4;

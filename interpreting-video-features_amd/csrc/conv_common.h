@@ -37,6 +37,9 @@ struct ConvKArgs {
   // gradients of several branches that live in different buffers
   const float* in2;
   int in2_ld, in2_coff, K0;
+  // second output window: columns [N0, Cout) go to out2 (forward epilogues of the implicit GEMM only)
+  float* out2;
+  int out2_ld, out2_coff, N0;
 };
 
 
@@ -145,6 +148,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     const bool nvalid = n < a.Cout;
     const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
     const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
+    // this column's destination: the main window, or the second one from column N0 on
+    const bool second = a.out2 != nullptr && n >= a.N0;
+    float* const ocol = second ? a.out2 + a.out2_coff + (n - a.N0) : a.out + a.out_coff + n;
+    const size_t oldim = second ? (size_t)a.out2_ld : (size_t)a.out_ld;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = row_base + i * 32 + 4 * lh;
@@ -158,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           const int r = half * 8 + q;
           const int m = mrow[q] = rowmap(rbase + (r & 3) + 8 * (r >> 2));
           const bool ok = nvalid && m >= 0;
-          old[q] = (a.accumulate && ok) ? a.out[(size_t)m * a.out_ld + a.out_coff + n] : 0.f;
+          old[q] = (a.accumulate && ok) ? ocol[(size_t)m * oldim] : 0.f;
           gate[q] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
         }
 #pragma unroll
@@ -168,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           float v = acc[i][j][half * 8 + q] * sc + sh + old[q];
           if (a.relu) v = v > 0.f ? v : 0.f;
           if (!(gate[q] > 0.f)) v = 0.f;
-          a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+          ocol[(size_t)m * oldim] = v;
         }
       }
     }

@@ -57,7 +57,10 @@ struct Op {
   int k[3], s[3], p[3];
   size_t idx_off = 0;  // pool arg-max bytes offset (in bytes, inside workspace)
   int var_fwd = IVF_CONV_AUTO, var_bwd = IVF_CONV_AUTO;   // tuned kernel variants
-  bool fwd_group = false;   // forward: the fused b1a+b2a conv (weights: convs[conv].grp_*)
+  bool fwd_group = false;   // forward: the fused b0|b1a|b2a GEMM (weights: convs[conv].grp_*): columns [0, n0) -> dst,
+                            // columns [n0, cout) -> dst2 (one read of the module input for the three 1x1x1 units)
+  bool fwd_skip = false;    // forward: nothing to do here (b0: covered by the fused GEMM)
+  int dst2 = -1, n0 = 0;
   bool bwd_skip = false;    // backward: nothing to do here (covered by the fused GEMM below)
   bool bwd_fused = false;   // backward: the fused b0+b1a+b2a GEMM; second gradient source = src2
   int src2 = -1;
@@ -213,8 +216,11 @@ static int build_plan(ivf_i3d* n) {
     {
       ConvLayer& A = n->convs[l1a];
       ConvLayer& Bq = n->convs[l2a];
-      A.grp_owner = l1a; A.grp_row = 0; A.grp_rows = t[2] + t[4];
-      Bq.grp_owner = l1a; Bq.grp_row = t[2]; Bq.grp_rows = t[2] + t[4];
+      const int gr = t[1] + t[2] + t[4];   // rows of the forward group [b0 | b1a | b2a]
+      ConvLayer& Z = n->convs[l0];
+      Z.grp_owner = l1a; Z.grp_row = 0; Z.grp_rows = gr;
+      A.grp_owner = l1a; A.grp_row = t[1]; A.grp_rows = gr;
+      Bq.grp_owner = l1a; Bq.grp_row = t[1] + t[2]; Bq.grp_rows = gr;
       const int kt = t[1] + t[2] + t[4];
       n->convs[l0].fus_owner = l0; n->convs[l0].fus_koff = 0; n->convs[l0].fus_ktotal = kt;
       A.fus_owner = l0; A.fus_koff = t[1]; A.fus_ktotal = kt;
@@ -222,15 +228,18 @@ static int build_plan(ivf_i3d* n) {
     }
     const size_t first_op = n->ops.size();
     b.conv_op(l0, x, 0, y, 0);
-    n->ops.back().side_fwd = true;
+    n->ops.back().fwd_skip = true;          // forward: part of the fused GEMM below
+    n->ops.back().flops_per_clip = 0.0;     // (counted there)
     n->ops.back().bwd_fused = true;
     n->ops.back().src2 = t12;
     n->ops.back().flops_bwd_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[1] + t[2] + t[4]);
-    b.conv_op(l1a, x, 0, t12, 0);          // forward: the fused [b1a | b2a] conv
+    b.conv_op(l1a, x, 0, y, 0);            // forward: the fused [b0 | b1a | b2a] GEMM, b0 -> y, [b1a | b2a] -> t12
     n->ops.back().fwd_group = true;
     n->ops.back().bwd_skip = true;
-    n->ops.back().cout = t[2] + t[4];
-    n->ops.back().flops_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[2] + t[4]);
+    n->ops.back().dst2 = t12;
+    n->ops.back().n0 = t[1];
+    n->ops.back().cout = t[1] + t[2] + t[4];
+    n->ops.back().flops_per_clip = 2.0 * s.T * s.H * s.W * (double)t[0] * (t[1] + t[2] + t[4]);
     n->bufs[x].consumers--;               // its backward is part of the fused GEMM (counted via b0)
     b.conv_op(l1b, t12, 0, y, t[1]);
     b.conv_op(l2b, t12, t[2], y, t[1] + t[3]);
@@ -368,7 +377,12 @@ static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
   d->relu = 1;
   d->math = n->cfg.math;
   d->variant = o.var_fwd;
-  (void)0;   // (for the fused [b1a | b2a] op o.cout already spans both units)
+  if (o.dst2 >= 0) {   // the fused [b0 | b1a | b2a] GEMM: o.cout spans the three units
+    d->N0 = o.n0;
+    d->out2 = n->act(o.dst2);
+    d->out2_ld = n->bufs[o.dst2].C;
+    d->out2_coff = 0;
+  }
 }
 
 static void fill_conv_bwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc* d) {
@@ -476,6 +490,7 @@ static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream
       lane.join();
       module = o.module;
     }
+    if (o.fwd_skip) continue;
     hipStream_t st = o.side_fwd ? lane.side() : s;
     prof_set_site(o.type == Op::CONV ? 2 * (int)(&o - n->ops.data()) : -1);
     if (o.type == Op::CONV) {
@@ -886,7 +901,7 @@ extern "C" int ivf_i3d_site_name(const ivf_i3d_t* net, int site, char* name64) {
   IVF_CHECK_ARG(o.type == Op::CONV, "i3d_site_name: site %d is not a convolution", site);
   const ConvLayer& L = net->convs[o.conv];
   std::string nm = L.name;
-  if (!(site & 1) && o.fwd_group) nm = L.name.substr(0, L.name.rfind('.')) + ".b1a|b2a";
+  if (!(site & 1) && o.fwd_group) nm = L.name.substr(0, L.name.rfind('.')) + ".b0|b1a|b2a";
   if ((site & 1) && o.bwd_fused) nm = L.name.substr(0, L.name.rfind('.')) + ".b0|b1a|b2a";
   nm += (site & 1) ? " backward-data" : " forward";
   strncpy(name64, nm.c_str(), 63);
@@ -932,6 +947,7 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
     const ConvLayer& L = net->convs[o.conv];
     for (int dir = 0; dir < 2 && rc == IVF_OK; ++dir) {
       if (dir == 1 && o.bwd_skip) continue;
+      if (dir == 0 && o.fwd_skip) continue;
       ivf_conv3d_desc d;
       int ids[64];
       int* slot = dir == 0 ? &o.var_fwd : &o.var_bwd;

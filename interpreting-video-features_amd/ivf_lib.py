@@ -28,7 +28,8 @@ class ConvDesc(Structure):
         "B", "Ti", "Hi", "Wi", "Cin", "in_ld", "in_coff", "To", "Ho", "Wo", "Cout", "out_ld",
         "out_coff", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "relu", "accumulate",
         "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math", "variant",
-        "K0", "in2_ld", "in2_coff")] + [("in2", c_void_p)]
+        "K0", "in2_ld", "in2_coff")] + [("in2", c_void_p)] + [(n, c_int) for n in ("N0", "out2_ld", "out2_coff")] + \
+        [("out2", c_void_p)]
 
 
 class BwdGeom(Structure):

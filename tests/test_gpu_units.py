@@ -350,6 +350,54 @@ def test_pointwise_conv_two_sources(k0, k1, cout, thw, math):
     assert ran >= 3
 
 
+@pytest.mark.parametrize("cin,n0,n1,thw,math", [(40, 24, 50, (3, 7, 9), "bf16x3"), (64, 112, 40, (2, 5, 11), "bf16x3"),
+                                                (40, 24, 50, (3, 7, 9), "fp32")])
+def test_conv_two_output_windows(cin, n0, n1, thw, math):
+    """ivf_conv3d_desc.out2 / N0: one GEMM whose columns [0, N0) land in one buffer and [N0, Cout) in another (the
+    forward of an Inception module's b0 | b1a | b2a), N0 off the 32-column tile grid, with the BN + ReLU epilogue,
+    every implicit-GEMM tile; the bytes around both windows must stay untouched."""
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(13)
+    B, cout = 2, n0 + n1
+    x = torch.randn((B,) + thw + (cin,), generator=gen)
+    w = torch.randn(cout, cin, 1, 1, 1, generator=gen) * 0.1
+    scale = torch.rand(cout, generator=gen) + 0.5
+    shift = torch.randn(cout, generator=gen) * 0.1
+    ref = torch.relu(torch.einsum('bthwk,nk->bthwn', x.double(), w.view(cout, cin).double()) * scale.double() + shift.double())
+    mm = L.MATH_MODES[math]
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, 1, 1, 1, mm), device='cuda')
+    wd, scd, shd, xd = w.cuda(), scale.cuda(), shift.cuda(), x.cuda()
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, cin, cin, 1, 1, 1, mm, L.stream()))
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cin, cin, 0
+    d.To, d.Ho, d.Wo = thw
+    d.Cout, d.out_ld, d.out_coff = cout, n0 + 12, 8          # first window: channels [8, 8 + n0) of a wider buffer
+    d.kT = d.kH = d.kW = 1
+    d.sT = d.sH = d.sW = 1
+    d.relu, d.math = 1, mm
+    ids = (ctypes.c_int * 64)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    ran = 0
+    tol = 1e-4 if math == "bf16x3" else 1e-5
+    for v in list(ids)[:n]:
+        y1 = torch.full((B,) + thw + (n0 + 12,), 7.0, device='cuda')
+        y2 = torch.full((B,) + thw + (n1 + 4,), 9.0, device='cuda')
+        d.variant = v
+        d.N0, d.out2_ld, d.out2_coff, d.out2 = n0, n1 + 4, 4, y2.data_ptr()
+        rc = lib.ivf_conv3d(ctypes.byref(d), L.ptr(xd), L.ptr(wf), L.ptr(scd), L.ptr(shd), None, L.ptr(y1), L.stream())
+        if rc != 0:
+            continue   # the LDS-halo / pix4 variants refuse a second window
+        ran += 1
+        g1, g2 = y1.cpu(), y2.cpu()
+        assert bool((g1[..., :8] == 7.0).all()) and bool((g1[..., 8 + n0:] == 7.0).all()), f"variant {v}"
+        assert bool((g2[..., :4] == 9.0).all())
+        assert rel_err(g1[..., 8:8 + n0].double().numpy(), ref[..., :n0].numpy()) < tol, f"variant {v}"
+        assert rel_err(g2[..., 4:].double().numpy(), ref[..., n0:].numpy()) < tol, f"variant {v} (second window)"
+    assert ran >= 3
+
+
 @pytest.mark.parametrize("k,st,thw", [((1, 3, 3), (1, 2, 2), (3, 17, 20)), ((3, 3, 3), (2, 2, 2), (5, 15, 14)),
                                       ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 2, 2), (4, 15, 9)),
                                       ((2, 2, 2), (1, 2, 2), (4, 8, 7)), ((2, 2, 2), (2, 2, 2), (3, 7, 7))])
