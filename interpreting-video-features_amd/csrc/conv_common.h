@@ -142,6 +142,76 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     }
     return;
   }
+  // 16-byte form: the 4 lanes of a quad hold 4 adjacent columns of the same 4 rows; a 4x4 transpose inside the quad
+  // (DPP quad permutes) gives every lane ONE row and 4 adjacent columns, so a row group is stored by one
+  // global_store_dwordx4 per lane instead of four dword stores (a wave instruction still covers whole 128-byte row
+  // segments); the accumulate / gate reads become 16-byte loads the same way.  Same arithmetic per element.
+  const bool vec_ok = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && (col_base & 3) == 0 &&
+                      (!a.mask || (((a.mask_ld | a.mask_coff) & 3) == 0)) &&
+                      (!a.out2 || (((a.N0 | a.out2_ld | a.out2_coff) & 3) == 0));
+  if (vec_ok) {
+    const int q = li & 3;
+    auto quad_transpose = [&](float (&v)[4]) {
+      // stage 1: exchange across lane bit 0 (registers k <-> k^1), stage 2: across lane bit 1 (k <-> k^2)
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        const float send = (q & 1) ? v[k] : v[k + 1];
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, false));
+        if (q & 1) v[k] = recv; else v[k + 1] = recv;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float send = (q & 2) ? v[k] : v[k + 2];
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, false));
+        if (q & 2) v[k] = recv; else v[k + 2] = recv;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = col_base + j * 32 + li;
+      const int nq = n & ~3;                       // first column of this lane's quad (all or none of them valid)
+      const bool nvalid = nq < a.Cout;
+      const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+      const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
+      const bool second = a.out2 != nullptr && nq >= a.N0;
+      float* const ocol = second ? a.out2 + a.out2_coff + (nq - a.N0) : a.out + a.out_coff + nq;
+      const size_t oldim = second ? (size_t)a.out2_ld : (size_t)a.out_ld;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rbase = row_base + i * 32 + 4 * lh;
+        float4 old4[4], gate4[4];
+        int mrow[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int m = mrow[g] = rowmap(rbase + q + 8 * g);
+          const bool ok = nvalid && m >= 0;
+          old4[g] = (a.accumulate && ok) ? *reinterpret_cast<const float4*>(ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gate4[g] = (a.mask && ok) ? *reinterpret_cast<const float4*>(a.mask + (size_t)m * a.mask_ld + a.mask_coff + nq)
+                                    : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * sc + sh;
+          quad_transpose(v);     // v[k]: row rbase + q + 8g, column nq + k
+          const int m = mrow[g];
+          if (!nvalid || m < 0) continue;
+          const float o4[4] = {old4[g].x, old4[g].y, old4[g].z, old4[g].w};
+          const float g4[4] = {gate4[g].x, gate4[g].y, gate4[g].z, gate4[g].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = v[k] + o4[k];
+            if (a.relu) t = t > 0.f ? t : 0.f;
+            if (!(g4[k] > 0.f)) t = 0.f;
+            v[k] = t;
+          }
+          *reinterpret_cast<float4*>(ocol + (size_t)m * oldim) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = col_base + j * 32 + li;
