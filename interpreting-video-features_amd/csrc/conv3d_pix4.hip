@@ -243,7 +243,33 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
       const int wl = cw0 + 4 * lh;
       const size_t rowstride = (size_t)a.Wo * a.out_ld;
       float* obase = a.out + ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl) * a.out_ld + a.out_coff + cn0 + li;
-      if (t < a.To) {
+      const bool vec_ok = ((a.Cout | a.out_ld | a.out_coff) & 3) == 0;
+      if (t < a.To && vec_ok) {
+        // 16-byte stores: after a 4x4 transpose inside the lane quad (conv_common.h) lane q holds pixel
+        // w = wl + q of each of the 4 h rows and the quad's 4 adjacent channels
+        const int q = li & 3;
+        float* const qbase = a.out + ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl + q) * a.out_ld + a.out_coff;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = cn0 + j * 32 + li;
+          const int nq = n & ~3;
+          const bool nvalid = nq < a.Cout;
+          const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+          const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float x = acc[j][4 * g + k] * sc + sh;
+              v[k] = (a.relu && !(x > 0.f)) ? 0.f : x;
+            }
+            quad_transpose4(v, q);
+            if (!nvalid || hb + g >= a.Ho || wl + q >= a.Wo) continue;
+            *reinterpret_cast<float4*>(qbase + (size_t)g * rowstride + nq) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else if (t < a.To) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = cn0 + j * 32 + li;

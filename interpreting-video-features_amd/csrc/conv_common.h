@@ -67,6 +67,24 @@ __device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
 // 128) into each write group instead: disjoint banks.  Bijective on every aligned block of 8.
 __device__ __forceinline__ int perm8(int r) { return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3); }
 
+// 4x4 transpose inside a lane quad: lane q holds v[k] = M[q][k] on entry and M[k][q] on exit (two DPP quad
+// permutes per register pair).  All four lanes of the quad must be active.
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], int q) {
+  // stage 1: exchange across lane bit 0 (registers k <-> k^1), stage 2: across lane bit 1 (k <-> k^2)
+#pragma unroll
+  for (int k = 0; k < 4; k += 2) {
+    const float send = (q & 1) ? v[k] : v[k + 1];
+    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, false));
+    if (q & 1) v[k] = recv; else v[k + 1] = recv;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float send = (q & 2) ? v[k] : v[k + 2];
+    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, false));
+    if (q & 2) v[k] = recv; else v[k + 2] = recv;
+  }
+}
+
 // Epilogue shared by both arithmetic variants.  Lane holds column n = li of each 32x32 tile,
 // rows (r&3) + 8*(r>>2) + 4*lh.  Per tile all old-value / gate loads are issued before any
 // store (the accumulate path reads and writes the same buffer, which would otherwise
@@ -151,21 +169,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
                       (!a.out2 || (((a.N0 | a.out2_ld | a.out2_coff) & 3) == 0));
   if (vec_ok) {
     const int q = li & 3;
-    auto quad_transpose = [&](float (&v)[4]) {
-      // stage 1: exchange across lane bit 0 (registers k <-> k^1), stage 2: across lane bit 1 (k <-> k^2)
-#pragma unroll
-      for (int k = 0; k < 4; k += 2) {
-        const float send = (q & 1) ? v[k] : v[k + 1];
-        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, false));
-        if (q & 1) v[k] = recv; else v[k + 1] = recv;
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float send = (q & 2) ? v[k] : v[k + 2];
-        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, false));
-        if (q & 2) v[k] = recv; else v[k + 2] = recv;
-      }
-    };
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = col_base + j * 32 + li;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           float v[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * sc + sh;
-          quad_transpose(v);     // v[k]: row rbase + q + 8g, column nq + k
+          quad_transpose4(v, q);     // v[k]: row rbase + q + 8g, column nq + k
           const int m = mrow[g];
           if (!nvalid || m < 0) continue;
           const float o4[4] = {old4[g].x, old4[g].y, old4[g].z, old4[g].w};
