@@ -690,16 +690,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ probs,
     const int* __restrict__ target, const float* __restrict__ dout, float* __restrict__ score,
     float* __restrict__ dpooled_out, float* __restrict__ dfeat, int npos, int C, int K, int softmax,
-    int gate) {
+    int gate, int cper) {
+  // grid (clip, channel slice of `cper` channels): every block recomputes the K logit gradients of its clip (a few
+  // hundred flops) and finishes its own channels -- one block per clip left 3/4 of the chip idle
   extern __shared__ float sm[];
   float* dl = sm;        // K
-  float* dp = sm + K;    // C
+  float* dp = sm + K;    // cper
   __shared__ float dot;
   const int b = blockIdx.x;
+  const int c_lo = blockIdx.y * cper, c_hi = min(C, c_lo + cper);
   const int t = target ? target[b] : -1;
   const float* pr = probs + (size_t)b * K;
   if (threadIdx.x == 0) {
-    if (score && target) score[b] = pr[t];
+    if (score && target && blockIdx.y == 0) score[b] = pr[t];
     float s = 0.f;
     if (softmax) {
       if (dout) {
@@ -717,21 +720,23 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
   }
   __syncthreads();
   const float inv = 1.f / (float)npos;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < K; ++k) s += dl[k] * w[(size_t)k * C + c];
-    dp[c] = s * inv;
+    dp[c - c_lo] = s * inv;
     if (dpooled_out) dpooled_out[(size_t)b * C + c] = s;
   }
   __syncthreads();
   if (!dfeat) return;
   const float* f = feat + (size_t)b * npos * C;
   float* df = dfeat + (size_t)b * npos * C;
-  for (int i = threadIdx.x; i < npos * C; i += blockDim.x) {
-    int c = i % C;
-    float v = dp[c];
-    if (gate && !(f[i] > 0.f)) v = 0.f;
-    df[i] = v;
+  const int cw = c_hi - c_lo;
+  for (int i = threadIdx.x; i < npos * cw; i += blockDim.x) {
+    const int p = i / cw, cc = i - p * cw;
+    const size_t e = (size_t)p * C + c_lo + cc;
+    float v = dp[cc];
+    if (gate && !(f[e] > 0.f)) v = 0.f;
+    df[e] = v;
   }
 }
 
@@ -1010,9 +1015,11 @@ extern "C" int ivf_head_bwd(const float* feat, const float* w, const float* prob
   IVF_CHECK_ARG(!dfeat || feat, "head_bwd: feat required with dfeat");
   IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K) * 4 <= 64 * 1024,
                 "head_bwd: bad dims");
-  size_t shm = (size_t)(C + K) * sizeof(float);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, feat, w, probs,
-                     target, dout, score, dpooled, dfeat, npos, C, K, softmax, gate_relu);
+  // channel slices of 128 (at least 4 blocks per CU's worth of clips at small batch)
+  const int cper = C >= 256 ? 128 : C;
+  size_t shm = (size_t)(cper + K) * sizeof(float);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B, cdiv(C, cper)), dim3(256), shm, (hipStream_t)stream, feat, w, probs,
+                     target, dout, score, dpooled, dfeat, npos, C, K, softmax, gate_relu, cper);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
