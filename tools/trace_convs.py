@@ -22,11 +22,12 @@ for n in arch.ENDPOINTS[5:]:
     if n in arch.POOLS:
         k, s = arch.POOLS[n]; T, H, W = pool(n, k[0], k[1], s[0], s[1], T, H, W); continue
     cin, oc = arch.INCEPTION[n]
-    conv(n+'.b0', cin, oc[0], 1, 1, 1, T, H, W); ops[-1] = ops[-1] + ('fusedbwd', 2.0 * T * H * W * cin * (oc[0] + oc[1] + oc[3]))
-    conv(n+'.b12a', cin, oc[1] + oc[3], 1, 1, 1, T, H, W); ops[-1] = ops[-1] + ('skipbwd', 0)
+    # forward: ONE GEMM for b0 | b1a | b2a; backward: b0's op carries the fused backward GEMM, the group's is skipped
+    conv(n+'.b0', cin, oc[0], 1, 1, 1, T, H, W); ops[-1] = ops[-1] + ('fusedbwd', 2.0 * T * H * W * cin * (oc[0] + oc[1] + oc[3]), 'skipfwd')
+    conv(n+'.b0|1a|2a', cin, oc[0] + oc[1] + oc[3], 1, 1, 1, T, H, W); ops[-1] = ops[-1] + ('skipbwd', 0)
     conv(n+'.b1b', oc[1], oc[2], 3, 1, 1, T, H, W)
     conv(n+'.b2b', oc[3], oc[4], 3, 1, 1, T, H, W); pool(n+'.b3a', 3, 3, 1, 1, T, H, W); conv(n+'.b3b', cin, oc[5], 1, 1, 1, T, H, W)
-seq = [('fwd',) + o[:5] for o in ops]
+seq = [('fwd',) + o[:5] for o in ops if not (len(o) > 7 and o[7] == 'skipfwd')]
 for o in reversed(ops):
     if len(o) > 5 and o[5] == 'skipbwd': continue
     if len(o) > 5 and o[5] == 'fusedbwd': seq.append(('bwd', o[0] + '+1a+2a', o[6]) + o[2:5])
