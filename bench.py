@@ -40,7 +40,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
              "bf16x3": "bf16 dense MFMA (v_mfma_f32_32x32x16_bf16); every algorithmic FLOP costs 3 MFMA FLOPs "
                        "in the split-bf16 mode, so the fp32-equivalent ceiling is 833 TFLOP/s"}
-NCLASS = 64
+NCLASS = 96   # IVF_PROFILE_CLASSES
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 

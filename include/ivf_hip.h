@@ -437,7 +437,7 @@ int ivf_viz_dots(unsigned char* img, const float* mask_snapped, int T, int H, in
  * IVF_PROFILE_CLASSES entries indexed by kernel variant id (IVF_CONV_IGEMM_BASE + tile for
  * fp32, +3 for split-bf16; IVF_CONV_HALO_BASE + i): summed kernel milliseconds, launch count
  * and algorithmic FLOPs of the sampled launches. */
-#define IVF_PROFILE_CLASSES 64
+#define IVF_PROFILE_CLASSES 96
 int ivf_profile_enable(int every, int max_launches);
 int ivf_profile_disable(void);
 int ivf_profile_collect(double* kernel_ms_host, long long* launches_host, double* flops_host);

@@ -69,7 +69,7 @@ __device__ __forceinline__ void tile_hw(int p, int hw_pitch, int* h, int* w) {
 //    cover with 23 % of their rows outside the map) use raster order.
 template <int TT, int TH, int TW>
 __device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, int* w) {
-  if constexpr (TT == 4 && TH == 8 && TW == 8) {
+  if constexpr (TT == 4 && TW == 8) {   // (any TH: a tile is one h-row of the box)
     const int li = row & 31, q = li >> 2, ql = q & 3;
     const int sel = ((ql + 1) >> 1) & 1;
     *t = (q >> 2) ? 3 - sel : sel;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, i
 template <int TT, int TH, int TW>
 __host__ __device__ inline int halo_plane_rows(int HH, int HW) {
   int ps = HH * HW;
-  if (TT == 4 && TH == 8 && TW == 8) ps += (4 - ps % 8 + 8) % 8;
+  if (TT == 4 && TW == 8) ps += (4 - ps % 8 + 8) % 8;
   return ps;
 }
 
@@ -592,7 +592,9 @@ int conv_halo_supported(const ConvKArgs& a) {
 // 38: 4 32 32 x 32 2 (16) x4 taps   39: 4 32 64 x 32 2 (16) x4   40: 4 32 32 x 32 2 (16) x2   41: 2 32 32 x 32 2 (32) x2
 // 42: 4 64 32 x 64 1 (16) x2        43: 4 64 32 x 64 1 (32) x2   44: 4 32 32 x 32 1 (16) x4   45: 4 96 32 x 96 1 (16) x2
 // 46: 4 32 32 x 32 2 (32) x2 (k <= 3)   47: 4x4x14 box, 64 32 x 64 1 (32) x2
-int conv_halo_num_variants() { return 48; }
+// 4 x 7 x 8 boxes (7 one-h-row tiles, conflict-free like the 4 x 8 x 8 ones; exact in H on 28- and 14-row maps):
+// 48: 192 32 x 96 1 (32)   49: 128 32 x 64 1 (32)   50: 96 32 x 96 1 (16)   51: 64 32 x 64 1 (16)
+int conv_halo_num_variants() { return 52; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -644,6 +646,10 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 45: return launch_halo<4, 96, 32, 96, 1, 16, 8, 8, 2>(a, 45, s);
     case 46: return launch_halo<4, 32, 32, 32, 2, 32, 8, 8, 2>(a, 46, s);
     case 47: return launch_halo<4, 64, 32, 64, 1, 32, 4, 14, 2>(a, 47, s);
+    case 48: return launch_halo<4, 192, 32, 96, 1, 32, 7, 8>(a, 48, s);
+    case 49: return launch_halo<4, 128, 32, 64, 1, 32, 7, 8>(a, 49, s);
+    case 50: return launch_halo<4, 96, 32, 96, 1, 16, 7, 8>(a, 50, s);
+    case 51: return launch_halo<4, 64, 32, 64, 1, 16, 7, 8>(a, 51, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

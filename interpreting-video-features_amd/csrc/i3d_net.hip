@@ -949,11 +949,11 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
       if (dir == 1 && o.bwd_skip) continue;
       if (dir == 0 && o.fwd_skip) continue;
       ivf_conv3d_desc d;
-      int ids[64];
+      int ids[96];
       int* slot = dir == 0 ? &o.var_fwd : &o.var_bwd;
       *slot = IVF_CONV_AUTO;
       if (dir == 0) fill_conv_fwd(net, o, b, &d); else fill_conv_bwd(net, o, b, &d);
-      int nv = ivf_conv3d_variants(&d, ids, 64);
+      int nv = ivf_conv3d_variants(&d, ids, 96);
       float best = 1e30f;
       int best_id = IVF_CONV_AUTO;
       for (int k = 0; k < nv; ++k) {

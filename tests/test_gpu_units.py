@@ -273,8 +273,8 @@ def test_every_conv_variant_matches_torch(k, cin, cout, thw):
     d.pT = d.pH = d.pW = pf
     d.math = mm
     d.mask_ld, d.mask_coff = cout, 0
-    ids = (ctypes.c_int * 64)()
-    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    ids = (ctypes.c_int * 96)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96)
     assert n >= 3
     base = torch.randn((B,) + thw + (cout,), generator=gen).cuda()
     gate = (torch.rand((B,) + thw + (cout,), generator=gen) > 0.3).float().cuda()
@@ -329,8 +329,8 @@ def test_pointwise_conv_two_sources(k0, k1, cout, thw, math):
     d.sT = d.sH = d.sW = 1
     d.math = mm
     d.mask_ld, d.mask_coff = cout, 0
-    ids = (ctypes.c_int * 64)()
-    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    ids = (ctypes.c_int * 96)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96)
     base = torch.randn((B,) + thw + (cout + 4,), generator=gen)
     gate = (torch.rand((B,) + thw + (cout,), generator=gen) > 0.3).float()
     want = (base[..., 4:].double() + ref) * gate.double()
@@ -377,8 +377,8 @@ def test_conv_two_output_windows(cin, n0, n1, thw, math):
     d.kT = d.kH = d.kW = 1
     d.sT = d.sH = d.sW = 1
     d.relu, d.math = 1, mm
-    ids = (ctypes.c_int * 64)()
-    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 64)
+    ids = (ctypes.c_int * 96)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96)
     ran = 0
     tol = 1e-4 if math == "bf16x3" else 1e-5
     for v in list(ids)[:n]:
