@@ -12,6 +12,13 @@ for p in (PKG, ROOT):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Parity tests run the plans with the built-in per-layer kernel choice: the autotuner picks by timing, so its choice
+# (and with it the last bits of every sum) varies from box to box, and a gate that sits at the edge of the Adam
+# trajectory's sensitivity would pass on one GPU and fail on the next.  What the tuner may pick is covered by
+# test_every_conv_variant_matches_torch (each variant against torch fp64) and by
+# test_tuned_plan_matches_builtin_choice (a tuned plan against the untuned one, whole network).
+os.environ.setdefault("IVF_AUTOTUNE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

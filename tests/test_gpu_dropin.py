@@ -218,7 +218,7 @@ def test_sharded_searches_equal_unsharded():
         return ivf_search.pack_records(clip_ids, res, T)
 
     full = ivf_engine.I3DEngine(174, (3, T, 224, 224), max_batch=n, softmax=True)
-    full.load_state_dict(sd)                       # autotunes at batch n ("rank 0")
+    full.load_state_dict(sd, autotune=True)        # autotunes at batch n ("rank 0")
     want = ivf_shard.gather_records(run(full, ids))
     tuning = full.get_tuning()
     parts = []

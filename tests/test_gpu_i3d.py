@@ -207,6 +207,31 @@ def test_batch_rows_independent(s16):
     assert torch.equal(pab[1], pa[0])
 
 
+def test_tuned_plan_matches_builtin_choice(s16):
+    """A plan whose kernels were picked by the autotuner on this box against the plan the other parity tests run
+    (built-in choice): same logits to rounding, same input gradient up to the arg-max ties the last bits can flip."""
+    import ivf_engine
+    import ivf_recipe as R
+    tuned = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=2, softmax=True, math=s16.math)
+    tuned.load_state_dict(R.i3d_state_dict(num_classes=174), autotune=True)
+    assert tuned.get_tuning() != s16.get_tuning()      # the tuner did choose something
+    x = torch.from_numpy(np.stack([R.clip(7), R.clip(8)])).cuda()
+    tgt = torch.tensor([3, 11], dtype=torch.int32)
+    res = []
+    for eng in (s16, tuned):
+        probs, logits = eng.forward(x, want_logits=True)
+        score, dx = eng.backward(2, target=tgt)
+        res.append((logits.clone(), probs.clone(), score.clone(), dx.clone()))
+    tol = 1e-6 if s16.math == "fp32" else 2e-5
+    e_logits = rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
+    d0, d1 = res[0][3].double(), res[1][3].double()
+    e_dx = float((d1 - d0).norm() / d0.norm())
+    note(f"tuned vs built-in plan, {s16.math}: logits max-rel {e_logits:.2e}, dx L2 {e_dx:.2e}")
+    assert e_logits < tol
+    assert rel_err(res[1][2].cpu().numpy(), res[0][2].cpu().numpy()) < 10 * tol
+    assert e_dx < 5e-2      # (1.5e-2 measured: max-pool near-ties rerouted by last-bit differences, as in test_whole_chain_*)
+
+
 def test_side_stream_overlap_is_bit_identical(s16):
     """ivf_i3d_set_overlap: the pool / b0 / b3b branch of every Inception module on a side stream (fork/join per
     module) must not change a bit of the probabilities, the scores or the input gradient."""
