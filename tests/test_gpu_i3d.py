@@ -232,6 +232,27 @@ def test_tuned_plan_matches_builtin_choice(s16):
     assert e_dx < 5e-2      # (1.5e-2 measured: max-pool near-ties rerouted by last-bit differences, as in test_whole_chain_*)
 
 
+def test_tuned_plan_matches_builtin_choice_k32(k32):
+    """The same on the KTH geometry (120 x 160 frames, odd map sizes: partial boxes in every kernel family)."""
+    import ivf_engine
+    import ivf_recipe as R
+    tuned = ivf_engine.I3DEngine(6, (3, 32, 120, 160), max_batch=1, head_hw=(4, 5), head_time_base=4, softmax=True,
+                                 math=k32.math)
+    tuned.load_state_dict(R.i3d_state_dict(num_classes=6, tag='i3d_kth'), autotune=True)
+    x = torch.from_numpy(R.clip(5, 3, 32, 120, 160))[None].cuda()
+    res = []
+    for eng in (k32, tuned):
+        probs, logits = eng.forward(x, want_logits=True)
+        score, dx = eng.backward(1, target=torch.tensor([2], dtype=torch.int32))
+        res.append((logits.clone(), dx.clone()))
+    e_logits = rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
+    d0, d1 = res[0][1].double(), res[1][1].double()
+    e_dx = float((d1 - d0).norm() / d0.norm())
+    note(f"tuned vs built-in plan (K32), {k32.math}: logits max-rel {e_logits:.2e}, dx L2 {e_dx:.2e}")
+    assert e_logits < (1e-6 if k32.math == "fp32" else 2e-5)
+    assert e_dx < 5e-2
+
+
 def test_side_stream_overlap_is_bit_identical(s16):
     """ivf_i3d_set_overlap: the pool / b0 / b3b branch of every Inception module on a side stream (fork/join per
     module) must not change a bit of the probabilities, the scores or the input gradient."""
