@@ -153,6 +153,14 @@ typedef struct {
    * module's b0 | b1a | b2a).  Served by the implicit-GEMM tiles only. */
   int N0, out2_ld, out2_coff;
   float* out2;
+  /* 1-bit ReLU gates (1 byte per 8 channels, rows of gate_*_ld BYTES; channel offsets are multiples of 8 and so is
+   * Cout / N0).  A forward epilogue can record (value > 0) of what it stores: gate_out for the `out` window,
+   * gate_out2 for the `out2` window.  A backward epilogue can take its gate from such a record (gate_in) instead
+   * of re-reading the fp32 activation through `relu_mask` -- 1/32 of the bytes.  All optional (null = off). */
+  unsigned char* gate_out;
+  unsigned char* gate_out2;
+  const unsigned char* gate_in;
+  int gate_out_ld, gate_out_coff, gate_out2_ld, gate_in_ld, gate_in_coff;
 } ivf_conv3d_desc;
 
 /* Kernel variants: tile shapes of the plain implicit GEMM (IVF_CONV_IGEMM_BASE + 0..2) and of

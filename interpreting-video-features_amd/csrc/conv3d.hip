@@ -606,6 +606,25 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     IVF_CHECK_ARG(d->variant == IVF_CONV_AUTO || (d->variant >= IVF_CONV_IGEMM_BASE && d->variant < IVF_CONV_PIX4),
                   "conv3d: a second output window is served by the implicit-GEMM tiles only");
   }
+  a.gbo = d->gate_out; a.gbo2 = d->gate_out2; a.gbi = d->gate_in;
+  a.gbo_ld = d->gate_out_ld; a.gbo_coff = d->gate_out_coff; a.gbo2_ld = d->gate_out2_ld;
+  a.gbi_ld = d->gate_in_ld; a.gbi_coff = d->gate_in_coff;
+  if (d->gate_out || d->gate_out2 || d->gate_in) {
+    IVF_CHECK_ARG(!d->d2s && (d->Cout & 7) == 0 && (d->out_ld & 3) == 0 && (d->out_coff & 3) == 0,
+                  "conv3d: 1-bit gates need Cout %% 8 == 0 and 4-aligned output rows (the 16-byte epilogue)");
+    IVF_CHECK_ARG(d->variant != IVF_CONV_PIX4, "conv3d: the pix4 kernel does not record 1-bit gates");
+    IVF_CHECK_ARG(!d->out2 || ((d->N0 | d->out2_ld | d->out2_coff) & 3) == 0, "conv3d: 1-bit gates with out2 need 4-aligned windows");
+  }
+  if (d->gate_out || d->gate_out2) {
+    IVF_CHECK_ARG(!d->accumulate && relu_mask == nullptr && !d->gate_in,
+                  "conv3d: gate_out / gate_out2 are forward-epilogue records (no accumulate / relu_mask / gate_in)");
+    IVF_CHECK_ARG(!d->gate_out || ((d->gate_out_coff & 7) == 0 && d->gate_out_ld > 0), "conv3d: gate_out window must be 8-aligned");
+    IVF_CHECK_ARG(!d->gate_out2 || (d->out2 && (d->N0 & 7) == 0 && (d->out2_coff & 7) == 0 && d->gate_out2_ld > 0),
+                  "conv3d: gate_out2 needs out2 with 8-aligned N0 / out2_coff");
+  }
+  if (d->gate_in)
+    IVF_CHECK_ARG(relu_mask == nullptr && (d->gate_in_coff & 3) == 0 && d->gate_in_ld > 0,
+                  "conv3d: gate_in replaces relu_mask (give one of them) and needs a 4-aligned channel offset");
   IVF_CHECK_ARG(d->math == 0 || d->math == 1, "conv3d: math must be 0 (fp32 MFMA) or 1 (split-bf16 x3)");
   a.ldw = pack_ldw(a.K, d->math);
   a.wbf = reinterpret_cast<const unsigned short*>(w_packed);
@@ -639,7 +658,7 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
     return conv_igemm_launch_variant(a, d->math, d->variant - IVF_CONV_IGEMM_BASE, (hipStream_t)stream);
   }
   if (d->math == 1 && !no_halo && !d->out2 && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
-  if (d->math == 1 && !no_halo && !d->out2 && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
+  if (d->math == 1 && !no_halo && !d->out2 && !a.gbo && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
 
@@ -740,7 +759,7 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   if (d->out2) return n;   // second output window: implicit-GEMM tiles only
   if (d->math == 1 && conv_halo_supported(a))
     for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
-  if (d->math == 1 && conv_pix4_supported(a) && n < max_ids) ids[n++] = IVF_CONV_PIX4;
+  if (d->math == 1 && conv_pix4_supported(a) && !d->gate_out && n < max_ids) ids[n++] = IVF_CONV_PIX4;
   return n;
 }
 

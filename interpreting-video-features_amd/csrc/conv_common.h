@@ -40,6 +40,11 @@ struct ConvKArgs {
   // second output window: columns [N0, Cout) go to out2 (forward epilogues of the implicit GEMM only)
   float* out2;
   int out2_ld, out2_coff, N0;
+  // 1-bit ReLU gates (ivf_conv3d_desc.gate_*): written by a forward epilogue, read by a backward one
+  unsigned char* gbo;        // record for the `out` window (row = gbo_ld bytes, first channel gbo_coff)
+  unsigned char* gbo2;       // record for the `out2` window (first channel 0 of its buffer + out2_coff)
+  const unsigned char* gbi;  // gate of the gradient being written (instead of `mask`)
+  int gbo_ld, gbo_coff, gbo2_ld, gbi_ld, gbi_coff;
 };
 
 
@@ -183,6 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
       for (int i = 0; i < TM; ++i) {
         const int rbase = row_base + i * 32 + 4 * lh;
         float4 old4[4], gate4[4];
+        unsigned gnib[4];     // 1-bit gates of this lane's 4 columns (all set when there is no bit record)
         int mrow[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -191,6 +197,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           old4[g] = (a.accumulate && ok) ? *reinterpret_cast<const float4*>(ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
           gate4[g] = (a.mask && ok) ? *reinterpret_cast<const float4*>(a.mask + (size_t)m * a.mask_ld + a.mask_coff + nq)
                                     : make_float4(1.f, 1.f, 1.f, 1.f);
+          unsigned nib = 15u;
+          if (a.gbi && ok) {
+            const int c = a.gbi_coff + nq;
+            nib = ((unsigned)a.gbi[(size_t)m * a.gbi_ld + (c >> 3)] >> (c & 4)) & 15u;
+          }
+          gnib[g] = nib;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -199,6 +211,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * sc + sh;
           quad_transpose4(v, q);     // v[k]: row rbase + q + 8g, column nq + k
           const int m = mrow[g];
+          if (a.gbo || a.gbo2) {
+            // forward record of (stored value > 0): this lane's 4 columns are a nibble, the lane 4 up (same row, next
+            // 4 columns) supplies the other half of the byte; even quads write.  (No accumulate / gate here.)
+            unsigned nib = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float t = v[k];
+              if (a.relu) t = t > 0.f ? t : 0.f;
+              nib |= (t > 0.f ? 1u : 0u) << k;
+            }
+            const unsigned hi = (unsigned)__shfl_down((int)nib, 4, 64);
+            if (nvalid && m >= 0 && ((li >> 2) & 1) == 0) {
+              if (second) {
+                if (a.gbo2) a.gbo2[(size_t)m * a.gbo2_ld + ((a.out2_coff + nq - a.N0) >> 3)] = (unsigned char)(nib | (hi << 4));
+              } else if (a.gbo) {
+                a.gbo[(size_t)m * a.gbo_ld + ((a.gbo_coff + nq) >> 3)] = (unsigned char)(nib | (hi << 4));
+              }
+            }
+          }
           if (!nvalid || m < 0) continue;
           const float o4[4] = {old4[g].x, old4[g].y, old4[g].z, old4[g].w};
           const float g4[4] = {gate4[g].x, gate4[g].y, gate4[g].z, gate4[g].w};
@@ -206,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           for (int k = 0; k < 4; ++k) {
             float t = v[k] + o4[k];
             if (a.relu) t = t > 0.f ? t : 0.f;
-            if (!(g4[k] > 0.f)) t = 0.f;
+            if (!(g4[k] > 0.f) || !((gnib[g] >> k) & 1u)) t = 0.f;
             v[k] = t;
           }
           *reinterpret_cast<float4*>(ocol + (size_t)m * oldim) = make_float4(v[0], v[1], v[2], v[3]);

@@ -23,6 +23,10 @@ struct ActBuf {
   int T, H, W, C;     // channels-last [B,T,H,W,C]
   bool relu_out;      // produced by Unit3D ReLU (or a concat of such)
   size_t act_off = 0, grad_off = 0;   // float offsets into the workspace
+  // 1-bit ReLU gate record (1 byte per 8 channels, written by the forward epilogues of the producers): kept for
+  // buffers whose gradient a convolution gates, so the backward reads 1/32 of the bytes of the fp32 activation
+  bool need_gate = false;
+  size_t gate_off = 0;                // byte offset into the workspace
   int consumers = 0;
   std::string name;
   size_t per_clip() const { return (size_t)T * H * W * C; }
@@ -104,6 +108,7 @@ struct ivf_i3d {
 
   float* act(int i) const { return (float*)ws + bufs[i].act_off; }
   float* grad(int i) const { return (float*)ws + bufs[i].grad_off; }
+  unsigned char* gatebits(int i) const { return (unsigned char*)ws + bufs[i].gate_off; }
   template <class T>
   T* at(size_t off) const { return (T*)(ws + off); }
 };
@@ -338,6 +343,22 @@ static int build_plan(ivf_i3d* n) {
       const ActBuf& d = n->bufs[o.dst];
       o.idx_off = takeb(B * d.per_clip());
     }
+  static const bool no_gate_bits = getenv("IVF_NO_GATE_BITS") != nullptr;   // A/B switch for measurements
+  for (const auto& o : n->ops)
+    if (o.type == Op::CONV && !o.bwd_skip && o.bwd_mask && (n->bufs[o.src].C & 7) == 0 && !no_gate_bits)
+      n->bufs[o.src].need_gate = true;
+  // every producer of such a buffer must be able to record the bits: an implicit-GEMM / LDS-halo epilogue writing
+  // an 8-aligned channel window (the stem's pix4 kernel and the pools cannot)
+  for (const auto& o : n->ops) {
+    if (o.type == Op::POOL) n->bufs[o.dst].need_gate = false;
+    if (o.type == Op::CONV && ((o.dst_coff | o.cout | o.n0) & 7)) {
+      n->bufs[o.dst].need_gate = false;
+      if (o.dst2 >= 0) n->bufs[o.dst2].need_gate = false;
+    }
+    if (o.type == Op::CONV && o.cin == 4 && o.s[1] == 2) n->bufs[o.dst].need_gate = false;   // the stem (pix4)
+  }
+  for (auto& bf : n->bufs)
+    if (bf.need_gate) bf.gate_off = takeb(B * bf.per_clip() / 8);
   const int K = c.num_classes, T = c.T;
   n->off_logits = takeb(B * K * 4);
   n->off_probs = takeb(B * K * 4);
@@ -382,6 +403,15 @@ static void fill_conv_fwd(const ivf_i3d* n, const Op& o, int b, ivf_conv3d_desc*
     d->out2 = n->act(o.dst2);
     d->out2_ld = n->bufs[o.dst2].C;
     d->out2_coff = 0;
+    if (n->bufs[o.dst2].need_gate) {
+      d->gate_out2 = n->gatebits(o.dst2);
+      d->gate_out2_ld = n->bufs[o.dst2].C / 8;
+    }
+  }
+  if (t.need_gate) {
+    d->gate_out = n->gatebits(o.dst);
+    d->gate_out_ld = t.C / 8;
+    d->gate_out_coff = o.dst_coff;
   }
 }
 
@@ -557,8 +587,15 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
       const ConvLayer& L = n->convs[o.conv];
       ivf_conv3d_desc d;
       fill_conv_bwd(n, o, b, &d);
+      const float* fgate = gate;
+      if (gate && n->bufs[o.src].need_gate) {   // the 1-bit record instead of the fp32 activation
+        d.gate_in = n->gatebits(o.src);
+        d.gate_in_ld = n->bufs[o.src].C / 8;
+        d.gate_in_coff = o.src_coff;
+        fgate = nullptr;
+      }
       prof_set_flops((o.bwd_fused ? o.flops_bwd_per_clip : o.flops_per_clip) * b);
-      rc = ivf_conv3d(&d, n->grad(o.dst), n->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr, nullptr, gate,
+      rc = ivf_conv3d(&d, n->grad(o.dst), n->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr, nullptr, fgate,
                       n->grad(o.src), st);
     } else {
       ivf_pool3d_desc d;
@@ -965,8 +1002,14 @@ extern "C" int ivf_i3d_autotune(ivf_i3d_t* net, int b, int reps, ivf_stream_t st
                                             net->act(o.dst), s)
                                : ivf_conv3d(&d, net->act(o.src), net->warena + L.wf_off, net->warena + L.scale_off,
                                             net->warena + L.shift_off, nullptr, net->act(o.dst), s);
+          const bool bits = o.bwd_mask && net->bufs[o.src].need_gate;
+          if (bits) {
+            d.gate_in = net->gatebits(o.src);
+            d.gate_in_ld = net->bufs[o.src].C / 8;
+            d.gate_in_coff = o.src_coff;
+          }
           return ivf_conv3d(&d, net->grad(o.dst), net->warena + (o.bwd_fused ? L.fus_wb_off : L.wb_off), nullptr,
-                            nullptr, o.bwd_mask ? net->act(o.src) : nullptr, net->grad(o.src), s);
+                            nullptr, (o.bwd_mask && !bits) ? net->act(o.src) : nullptr, net->grad(o.src), s);
         };
         if (run() != IVF_OK) continue;          // variant not applicable to this shape
         (void)hipEventRecord(e0, s);

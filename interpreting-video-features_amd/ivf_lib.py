@@ -29,7 +29,8 @@ class ConvDesc(Structure):
         "out_coff", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "relu", "accumulate",
         "mask_ld", "mask_coff", "d2s", "dT", "dH", "dW", "dC", "bsT", "bsH", "bsW", "math", "variant",
         "K0", "in2_ld", "in2_coff")] + [("in2", c_void_p)] + [(n, c_int) for n in ("N0", "out2_ld", "out2_coff")] + \
-        [("out2", c_void_p)]
+        [("out2", c_void_p), ("gate_out", c_void_p), ("gate_out2", c_void_p), ("gate_in", c_void_p)] + \
+        [(n, c_int) for n in ("gate_out_ld", "gate_out_coff", "gate_out2_ld", "gate_in_ld", "gate_in_coff")]
 
 
 class BwdGeom(Structure):

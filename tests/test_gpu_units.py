@@ -398,6 +398,80 @@ def test_conv_two_output_windows(cin, n0, n1, thw, math):
     assert ran >= 3
 
 
+@pytest.mark.parametrize("k,cin,n0,n1,thw", [(1, 40, 24, 48, (3, 7, 9)), (3, 32, 48, 0, (4, 9, 10)), (1, 64, 112, 40, (2, 5, 11))])
+def test_one_bit_relu_gates(k, cin, n0, n1, thw):
+    """ivf_conv3d_desc.gate_out / gate_out2 / gate_in: a forward epilogue records (stored value > 0) as 1 bit per
+    element (1 byte per 8 channels), for the main and the second output window; a backward epilogue gated by that
+    record must equal, bit for bit, the one gated by the fp32 activation (relu_mask).  Every variant that serves the
+    shape; channel windows inside wider rows; ragged positions."""
+    import torch.nn.functional as F
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(17)
+    B, cout = 2, n0 + n1
+    mm = L.MATH_MODES["bf16x3"]
+    x = torch.randn((B,) + thw + (cin,), generator=gen).cuda()
+    w = (torch.randn(cout, cin, k, k, k, generator=gen) * 0.1).cuda()
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, k, k, k, mm), device='cuda')
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(w), L.ptr(wf), cout, cin, cin, k, k, k, mm, L.stream()))
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cin, cin, 0
+    d.To, d.Ho, d.Wo = thw
+    d.kT = d.kH = d.kW = k
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = (k - 1) // 2
+    d.relu, d.math = 1, mm
+    d.Cout, d.out_ld, d.out_coff = cout, n0 + 16, 8
+    ids = (ctypes.c_int * 96)()
+    P = B * thw[0] * thw[1] * thw[2]
+    ran = 0
+    for v in list(ids)[:lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96)]:
+        y1 = torch.zeros((B,) + thw + (n0 + 16,), device='cuda')
+        y2 = torch.zeros((B,) + thw + (max(n1, 8) + 8,), device='cuda')
+        b1 = torch.full((P, (n0 + 16) // 8), 0xAA, dtype=torch.uint8, device='cuda')
+        b2 = torch.full((P, (max(n1, 8) + 8) // 8), 0xAA, dtype=torch.uint8, device='cuda')
+        d.variant = v
+        d.gate_out, d.gate_out_ld, d.gate_out_coff = b1.data_ptr(), (n0 + 16) // 8, 8
+        if n1:
+            d.N0, d.out2_ld, d.out2_coff, d.out2 = n0, n1 + 8, 8, y2.data_ptr()
+            d.gate_out2, d.gate_out2_ld = b2.data_ptr(), (n1 + 8) // 8
+        rc = lib.ivf_conv3d(ctypes.byref(d), L.ptr(x), L.ptr(wf), None, None, None, L.ptr(y1), L.stream())
+        if rc != 0:
+            continue
+        ran += 1
+        for y, bits, c0, n in ((y1, b1, 8, n0), (y2, b2, 8, n1)):
+            if not n:
+                continue
+            want = (y.view(P, -1)[:, c0:c0 + n] > 0)
+            got = ((bits[:, :, None] >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1).bool().view(P, -1)
+            assert torch.equal(got[:, c0:c0 + n], want), f"variant {v}"
+            assert bool((bits[:, :c0 // 8] == 0xAA).all()) and bool((bits[:, (c0 + n) // 8:] == 0xAA).all()), f"variant {v}"
+        # consumer side: a 1x1x1 "backward" GEMM producing n0 channels, accumulate + gate, bits vs fp32 activation
+        if ran == 1:
+            gin = torch.randn(P, 32, generator=gen).cuda()
+            wb = (torch.randn(n0, 32, 1, 1, 1, generator=gen) * 0.1).cuda()
+            wbp = torch.empty(lib.ivf_conv3d_pack_fwd_elems(n0, 32, 1, 1, 1, mm), device='cuda')
+            L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wb), L.ptr(wbp), n0, 32, 32, 1, 1, 1, mm, L.stream()))
+            e = L.ConvDesc()
+            e.B, e.Ti, e.Hi, e.Wi = B, *thw
+            e.Cin, e.in_ld, e.in_coff = 32, 32, 0
+            e.To, e.Ho, e.Wo = thw
+            e.kT = e.kH = e.kW = 1
+            e.sT = e.sH = e.sW = 1
+            e.math, e.accumulate = mm, 1
+            e.Cout, e.out_ld, e.out_coff = n0, n0 + 16, 8
+            e.mask_ld, e.mask_coff = n0 + 16, 8
+            base = torch.randn((P, n0 + 16), generator=gen).cuda()
+            o1, o2 = base.clone(), base.clone()
+            L.check(lib.ivf_conv3d(ctypes.byref(e), L.ptr(gin), L.ptr(wbp), None, None, L.ptr(y1), L.ptr(o1), L.stream()))
+            e.gate_in, e.gate_in_ld, e.gate_in_coff = b1.data_ptr(), (n0 + 16) // 8, 8
+            L.check(lib.ivf_conv3d(ctypes.byref(e), L.ptr(gin), L.ptr(wbp), None, None, None, L.ptr(o2), L.stream()))
+            assert torch.equal(o1, o2)
+            assert bool((o1[:, 8:8 + n0][y1.view(P, -1)[:, 8:8 + n0] <= 0] == 0).all())
+    assert ran >= 3
+
+
 @pytest.mark.parametrize("k,st,thw", [((1, 3, 3), (1, 2, 2), (3, 17, 20)), ((3, 3, 3), (2, 2, 2), (5, 15, 14)),
                                       ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 2, 2), (4, 15, 9)),
                                       ((2, 2, 2), (1, 2, 2), (4, 8, 7)), ((2, 2, 2), (2, 2, 2), (3, 7, 7))])
