@@ -105,7 +105,11 @@ __host__ __device__ inline int halo_plane_rows(int HH, int HW) {
 // them without meeting.  Every barrier costs the MFMA pipe about 1000 idle cycles (the waves re-issue their fragment
 // reads together; profiles/r02_halo_phase_stamps.txt), which a narrow tile (32 columns: 6 MFMAs per wave per
 // tap) cannot amortise over one tap.
-template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH, int TH, int TW, int TPS>
+// DMA = the weight tiles go from global memory straight into LDS (global_load_lds_dwordx4: no register ring, no
+// ds_write_b128, no wait on the data inside the step): unpadded 64-byte rows, the 16-byte slot of a row XOR-ed
+// with (row >> 2) & 3 -- the permutation is applied to the SOURCE address of every lane (the DMA writes lane i's
+// 16 bytes at M0 + 16 i), and a lane's fragment address is a per-lane constant, so the tap loop pays nothing for it.
+template <int TT, int BN, int WROWS, int WCOLS, int KS, int BKH, int TH, int TW, int TPS, bool DMA>
 __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) void conv3d_halo_kernel(ConvKArgs a,
                                                                                                 int tilesT,
                                                                                                 int tilesH,
@@ -117,6 +121,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   constexpr int NT = WM * WN * KS * 64;
   constexpr int TM = WROWS / 32, TN = WCOLS / 32;
   constexpr int ROWB = (BKH + 8) * 2;   // bytes per LDS row per plane (80 / 48: conflict-free 16-byte reads)
+  constexpr int ROWB_B = DMA ? BKH * 2 : ROWB;   // weight rows: unpadded + swizzled in DMA mode
+  static_assert(!DMA || BKH == 32, "the LDS-DMA weight stream is written for 32-channel chunks");
   constexpr int G4 = BKH / 4;           // float4 groups per halo row
   constexpr int G8 = BKH / 8;           // 16-byte weight groups per row per plane
   constexpr int BLOADS = (TPS * KS * BN * G8 + NT - 1) / NT;   // 16-byte weight loads per thread per plane per step
@@ -130,7 +136,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   unsigned char* a_hi = smem;
   unsigned char* a_lo = smem + (size_t)HR * ROWB;
   unsigned char* b_base = smem + (size_t)2 * HR * ROWB;   // [2 buffers][TPS taps][KS groups][hi, lo][BN rows]
-  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * TPS * KS * BN * ROWB);   // [HR] input offset of a halo row / in_ld, or -1
+  int* rowoff = reinterpret_cast<int*>(b_base + (size_t)4 * TPS * KS * BN * ROWB_B);   // [HR] input offset of a halo row / in_ld, or -1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     const int row = BKH == 32 ? perm8(rem / G8) : rem / G8, g2 = rem % G8;
     const int n = min(n0 + row, a.Cout - 1);
     b_src[q] = sub < TPS ? n * a.ldw : 0;
-    b_dst[q] = sub < TPS ? ((sub * KS + grp) * 2 * BN + row) * ROWB + 16 * g2 : -1;
+    b_dst[q] = sub < TPS ? ((sub * KS + grp) * 2 * BN + row) * ROWB_B + 16 * g2 : -1;
     b_tap[q] = sub < TPS ? sub + grp * ntg : 0;
     b_c[q] = 8 * g2;
   }
@@ -236,12 +242,12 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     }
   };
   auto store_b = [&](int slot, int buf) __attribute__((always_inline)) {
-    unsigned char* bb = b_base + (size_t)buf * (TPS * KS * 2 * BN * ROWB);
+    unsigned char* bb = b_base + (size_t)buf * (TPS * KS * 2 * BN * ROWB_B);
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q) {
       if (b_dst[q] >= 0) {
         *reinterpret_cast<u32x4*>(bb + b_dst[q]) = rbh[slot][q];
-        *reinterpret_cast<u32x4*>(bb + b_dst[q] + BN * ROWB) = rbl[slot][q];
+        *reinterpret_cast<u32x4*>(bb + b_dst[q] + BN * ROWB_B) = rbl[slot][q];
       }
     }
   };
@@ -271,7 +277,41 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
   int abase[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) abase[i] = arow[i] * ROWB + 16 * lh;
-  const int bbase = (wn * WCOLS + li) * ROWB + 16 * lh;
+  // weight-fragment offsets of this lane inside a (tap, group) tile: column tile j, 16-channel slice ks
+  auto b_off = [&](int j, int ks) __attribute__((always_inline)) {
+    const int row = wn * WCOLS + j * 32 + li;
+    if constexpr (DMA) return row * ROWB_B + 16 * ((2 * ks + lh) ^ ((row >> 2) & 3));
+    else return row * ROWB_B + ks * 32 + 16 * lh;
+  };
+  // ---- LDS-DMA weight stream: piece p (16 bytes) of a buffer = [sub][group][plane][row][physical slot], i.e. byte 16 p
+  constexpr int NP = TPS * KS * 2 * BN * (BKH / 8), NI = NP / 64, NWV = NT / 64, MAXI = (NI + NWV - 1) / NWV;
+  int d_base[MAXI], d_tap[MAXI], d_c[MAXI];
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      const int p = (wave + k * NWV) * 64 + lane;
+      const int slot = p % G8, row = (p / G8) % BN, plane = (p / (G8 * BN)) & 1;
+      const int grp = (p / (G8 * BN * 2)) % KS, sb = p / (G8 * BN * 2 * KS);
+      d_base[k] = plane * (int)a.w_lo_off + min(n0 + row, a.Cout - 1) * a.ldw;
+      d_tap[k] = sb + grp * ntg;
+      d_c[k] = 8 * (slot ^ ((row >> 2) & 3));
+    }
+  }
+  const unsigned b_lds = (unsigned)(uintptr_t)b_base;   // LDS byte address (low half of the flat address)
+  auto dma_b = [&](int step, int buf, int c0) __attribute__((always_inline)) {
+    if constexpr (DMA) {
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k) {
+        if (wave + k * NWV >= NI) continue;   // (wave-uniform)
+        const int tap = min(step * TPS + d_tap[k], ntaps - 1);
+        int c = c0 + d_c[k];
+        c = c < a.Cin ? c : 0;
+        const unsigned short* g = a.wbf + (size_t)(d_base[k] + tap * a.Cin + c);
+        const unsigned dst = b_lds + (unsigned)buf * (unsigned)(TPS * KS * 2 * BN * ROWB_B) + (unsigned)(wave + k * NWV) * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(g));   // (m0 is reserved: the compiler keeps nothing in it)
+      }
+    }
+  };
   // One step = the TPS taps of an LDS weight buffer.  Narrow wave tiles (one MFMA tile, 6 MFMAs per tap) run a
   // software pipeline over the (tap, 16-channel slice) units of the step: the fragments of unit u+1 are in flight
   // while unit u's MFMAs issue, so a wave exposes one LDS round trip per step instead of two per slice.
@@ -281,16 +321,16 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     const int lt0 = step * TPS;
     const int nsub = min(TPS, min(ntg - lt0, ntaps - wk * ntg - lt0));   // valid taps of this wave's group in the step
     if (nsub <= 0) return;
-    const unsigned char* bstep = b_base + (size_t)(buf * TPS * KS + wk) * 2 * BN * ROWB;   // + sub * KS * 2 * BN * ROWB
+    const unsigned char* bstep = b_base + (size_t)(buf * TPS * KS + wk) * 2 * BN * ROWB_B;   // + sub * KS * 2 * BN * ROWB_B
     if constexpr (PIPELINED) {   // (a partial last chunk runs all NKS slices: channels past Cin are staged as zeros)
       bf16x8 fah[2], fal[2], fbh[2], fbl[2];
       auto issue = [&](int slot, int sub, int ks) __attribute__((always_inline)) {
         const int aoff = abase[0] + t_off + ks * 32;
-        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB + bbase + ks * 32;
+        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB_B + b_off(0, ks);
         fah[slot] = *reinterpret_cast<const bf16x8*>(a_hi + aoff);
         fal[slot] = *reinterpret_cast<const bf16x8*>(a_lo + aoff);
         fbh[slot] = *reinterpret_cast<const bf16x8*>(bh);
-        fbl[slot] = *reinterpret_cast<const bf16x8*>(bh + (size_t)BN * ROWB);
+        fbl[slot] = *reinterpret_cast<const bf16x8*>(bh + (size_t)BN * ROWB_B);
       };
       issue(0, 0, 0);
 #pragma unroll
@@ -315,8 +355,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #pragma unroll
       for (int sub = 0; sub < TPS; ++sub) {
         if (sub >= nsub) break;
-        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB + bbase;
-        const unsigned char* bl = bh + (size_t)BN * ROWB;
+        const unsigned char* bh = bstep + (size_t)sub * KS * 2 * BN * ROWB_B;
+        const unsigned char* bl = bh + (size_t)BN * ROWB_B;
         for (int ks = 0; ks < nks; ++ks) {
           bf16x8 fah[TM], fal[TM];
 #pragma unroll
@@ -327,7 +367,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const int off = j * 32 * ROWB + ks * 32;
+            const int off = b_off(j, ks);
             bf16x8 fbh = *reinterpret_cast<const bf16x8*>(bh + off);
             bf16x8 fbl = *reinterpret_cast<const bf16x8*>(bl + off);
 #pragma unroll
@@ -384,10 +424,13 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 
   for (int c0 = 0; c0 < a.Cin; c0 += BKH) {
     // weight tiles of the first PF taps start flying before the halo is staged
-    load_b(0, 0, c0);
-    load_b(1, 1, c0);
-    load_b(2, 2, c0);
+    if constexpr (!DMA) {
+      load_b(0, 0, c0);
+      load_b(1, 1, c0);
+      load_b(2, 2, c0);
+    }
     __syncthreads();   // everyone is done with the previous chunk's halo and weight buffers
+    dma_b(0, 0, c0);   // (DMA mode: the first step's tiles land in buffer 0 while the halo is staged)
     IVF_STAMP(st_s0);
     for (stage_base = 0; stage_base < ngroups; stage_base += NSTG * NT) {
       stage_load(c0);
@@ -398,7 +441,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     // `s_waitcnt vmcnt(0)` (staging registers reused by the fragment reads) out of the tap loop, where it would
     // drain the weight prefetch every step
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    store_b(0, 0);
+    if constexpr (!DMA) store_b(0, 0);
     __syncthreads();
     IVF_STAMP(st_s1);
     IVF_STAMP_ADD(1, st_s1, st_s0);
@@ -424,10 +467,21 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #endif
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
-    for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
-      tap_body(std::integral_constant<int, 0>{}, tap0);
-      tap_body(std::integral_constant<int, 1>{}, tap0);
-      tap_body(std::integral_constant<int, 2>{}, tap0);
+    if constexpr (DMA) {
+      // step t: the tiles of step t+1 start towards the other buffer (free since the barrier that ended step t-1),
+      // the MFMAs of step t run, then the wave waits for its own DMA and everybody meets
+      for (int tap = 0; tap < nsteps; ++tap) {
+        if (tap + 1 < nsteps) dma_b(tap + 1, (tap + 1) & 1, c0);
+        mma_tap(tap, tap & 1, nks);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    } else {
+      for (int tap0 = 0; tap0 < nsteps; tap0 += PF) {
+        tap_body(std::integral_constant<int, 0>{}, tap0);
+        tap_body(std::integral_constant<int, 1>{}, tap0);
+        tap_body(std::integral_constant<int, 2>{}, tap0);
+      }
     }
     IVF_STAMP(st_s2);
     IVF_STAMP_ADD(2, st_s2, st_s1);
@@ -531,12 +585,13 @@ extern "C" int ivf_debug_halo_stamps(unsigned long long* out8, int reset) {
 namespace ivf {
 #endif
 
-template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH = 8, int TW = 8, int TPS = 1>
+template <int TT, int BN, int WROWS, int WCOLS, int KS = 1, int BKH = 32, int TH = 8, int TW = 8, int TPS = 1, bool DMA = false>
 static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int NT = (TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64;
   constexpr int ROWB = (BKH + 8) * 2;
+  constexpr int ROWB_B = DMA ? BKH * 2 : ROWB;
   const int HR = (TT + a.kT - 1) * halo_plane_rows<TT, TH, TW>(TH + a.kH - 1, TW + a.kW - 1);
-  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * TPS * KS * 2 * BN * ROWB + (size_t)HR * sizeof(int);
+  const size_t shm = (size_t)2 * HR * ROWB + (size_t)2 * TPS * KS * 2 * BN * ROWB_B + (size_t)HR * sizeof(int);
   if (KS == 2 && (size_t)TT * TH * TW * BN * 4 > (size_t)2 * HR * ROWB) {
     set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
     return IVF_ERR_UNSUPPORTED;
@@ -547,7 +602,7 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS>),
+    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS, DMA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -555,10 +610,10 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   a.ntiles = cdiv(a.Cout, BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
   dim3 grid(a.mtiles * a.ntiles);
-  prof_name(IVF_CONV_HALO_BASE + variant_id, "conv3d_halo_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", TT, BN, WROWS, WCOLS, KS,
-            BKH, TH, TW, TPS);
+  prof_name(IVF_CONV_HALO_BASE + variant_id, "conv3d_halo_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%s>", TT, BN, WROWS, WCOLS, KS,
+            BKH, TH, TW, TPS, DMA ? "true" : "false");
   const bool timed = prof_begin(s, IVF_CONV_HALO_BASE + variant_id);
-  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
+  hipLaunchKernelGGL((conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS, DMA>), grid, dim3(NT), shm, s, a, tilesT, tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -594,7 +649,10 @@ int conv_halo_supported(const ConvKArgs& a) {
 // 46: 4 32 32 x 32 2 (32) x2 (k <= 3)   47: 4x4x14 box, 64 32 x 64 1 (32) x2
 // 4 x 7 x 8 boxes (7 one-h-row tiles, conflict-free like the 4 x 8 x 8 ones; exact in H on 28- and 14-row maps):
 // 48: 192 32 x 96 1 (32)   49: 128 32 x 64 1 (32)   50: 96 32 x 96 1 (16)   51: 64 32 x 64 1 (16)
-int conv_halo_num_variants() { return 52; }
+// weight tiles by LDS-DMA (global_load_lds_dwordx4, swizzled 64-byte rows):
+// 52: 4 192 32 x 96 1 (32) 8x8   53: same, 4x14   54: 4 128 32 x 64 1 (32) 4x14   55: 4 128 32 x 64 1 (32) 8x8
+// 56: 4 32 32 x 32 2 (32) 8x8    57: 4 128 32 x 64 1 (32) 7x8   58: 4 96 32 x 96 1 (32) 8x8   59: 4 64 32 x 64 1 (32) 8x8
+int conv_halo_num_variants() { return 60; }
 
 int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
   switch (v) {
@@ -650,6 +708,14 @@ int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s) {
     case 49: return launch_halo<4, 128, 32, 64, 1, 32, 7, 8>(a, 49, s);
     case 50: return launch_halo<4, 96, 32, 96, 1, 16, 7, 8>(a, 50, s);
     case 51: return launch_halo<4, 64, 32, 64, 1, 16, 7, 8>(a, 51, s);
+    case 52: return launch_halo<4, 192, 32, 96, 1, 32, 8, 8, 1, true>(a, 52, s);
+    case 53: return launch_halo<4, 192, 32, 96, 1, 32, 4, 14, 1, true>(a, 53, s);
+    case 54: return launch_halo<4, 128, 32, 64, 1, 32, 4, 14, 1, true>(a, 54, s);
+    case 55: return launch_halo<4, 128, 32, 64, 1, 32, 8, 8, 1, true>(a, 55, s);
+    case 56: return launch_halo<4, 32, 32, 32, 2, 32, 8, 8, 1, true>(a, 56, s);
+    case 57: return launch_halo<4, 128, 32, 64, 1, 32, 7, 8, 1, true>(a, 57, s);
+    case 58: return launch_halo<4, 96, 32, 96, 1, 32, 8, 8, 1, true>(a, 58, s);
+    case 59: return launch_halo<4, 64, 32, 64, 1, 32, 8, 8, 1, true>(a, 59, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;
