@@ -297,7 +297,6 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       d_c[k] = 8 * (slot ^ ((row >> 2) & 3));
     }
   }
-  const unsigned b_lds = (unsigned)(uintptr_t)b_base;   // LDS byte address (low half of the flat address)
   auto dma_b = [&](int step, int buf, int c0) __attribute__((always_inline)) {
     if constexpr (DMA) {
 #pragma unroll
@@ -307,8 +306,11 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
         int c = c0 + d_c[k];
         c = c < a.Cin ? c : 0;
         const unsigned short* g = a.wbf + (size_t)(d_base[k] + tap * a.Cin + c);
-        const unsigned dst = b_lds + (unsigned)buf * (unsigned)(TPS * KS * 2 * BN * ROWB_B) + (unsigned)(wave + k * NWV) * 1024u;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(g));   // (m0 is reserved: the compiler keeps nothing in it)
+        // the compiler's own LDS-DMA builtin: it owns M0 (destination = wave-uniform LDS base, lane i writes 16 bytes
+        // at base + 16 i) and knows that LDS is written
+        unsigned char* dst = b_base + (size_t)buf * (TPS * KS * 2 * BN * ROWB_B) + (size_t)(wave + k * NWV) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     }
   };
@@ -600,12 +602,8 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
     set_error("conv3d_halo: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS, DMA>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static LdsAttrOnce once;
+  IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&conv3d_halo_kernel<TT, BN, WROWS, WCOLS, KS, BKH, TH, TW, TPS, DMA>), 160 * 1024, once));
   const int tilesT = cdiv(a.To, TT), tilesH = cdiv(a.Ho, TH), tilesW = cdiv(a.Wo, TW);
   a.ntiles = cdiv(a.Cout, BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;

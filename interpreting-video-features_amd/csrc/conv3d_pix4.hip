@@ -304,12 +304,8 @@ int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s) {
     set_error("conv3d_pix4: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_pix4_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static LdsAttrOnce once;
+  IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&conv3d_pix4_kernel), 160 * 1024, once));
   const int tilesT = cdiv(a.To, P4_TT), tilesH = cdiv(a.Ho, P4_TH), tilesW = cdiv(a.Wo, P4_TW);
   a.ntiles = cdiv(a.Cout, P4_BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;

@@ -45,6 +45,17 @@ void prof_name(int variant, const char* fmt, ...);   // kernel name of a profile
     if (rc_ != IVF_OK) return rc_; \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `done` is the call site's static flag array
+struct LdsAttrOnce { bool done[32] = {}; };
+static inline int raise_lds_limit(const void* kernel, int bytes, LdsAttrOnce& once) {
+  int dev = 0;
+  IVF_CHECK_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 32 && once.done[dev]) return IVF_OK;
+  IVF_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev >= 0 && dev < 32) once.done[dev] = true;
+  return IVF_OK;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

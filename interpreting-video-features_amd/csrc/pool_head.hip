@@ -969,12 +969,8 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
   }
   // measured (16-channel slabs): the tiled gather wins 1.3-1.6x for every pool of the net
   if (!direct && shm <= 80 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      IVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maxpool_bwd_tiled_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      attr_set = true;
-    }
+    static LdsAttrOnce once;
+    IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&maxpool_bwd_tiled_kernel), 80 * 1024, once));
     long blocks = (long)a.B * t.nT * t.nH * t.nW * t.slabs;
     hipLaunchKernelGGL(maxpool_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), shm, (hipStream_t)stream, dy,
                        argmax, dx, relu_mask, accumulate, a, t, 0, 0, 0);

@@ -107,8 +107,8 @@ def find_masks_impl(dat_loader, model, hyper_params, lam1, lam2, N, temporalMask
                                     'GCHeatMap': host["gradcam"][j].numpy().astype(np.float32)})
             if runTempMask and write_files and visualise:
                 # smth:296-303 / KTH:354-367: heat-map strips with the mask dot row for both perturbation
-                # types (the dot row snaps `tmask` IN PLACE, so the returned masks are the snapped ones, as
-                # in the reference), then for KTH the perturbed frames as PNGs
+                # types (the dot row snaps a host copy: `tmask` keeps its sigmoid values, as the reference's
+                # CUDA time_mask does), then for KTH the perturbed frames as PNGs of the SOFT mask
                 import visualisation as viz
                 if doGradCam:
                     for kind in ("freeze", "reverse"):
@@ -118,7 +118,8 @@ def find_masks_impl(dat_loader, model, hyper_params, lam1, lam2, N, temporalMask
                     import mask as _mask
                     viz.vizualize_results(xs[j], _mask.perturb_sequence(xs, tmask, temporalMaskType)[j], tmask,
                                           rootDir=d, case=str(vid), markImgs=True, iterTest=False)
-            if runTempMask:
+            # smth:303 appends only when both Grad-CAM and the mask search ran; KTH:367 whenever the search ran
+            if runTempMask and (doGradCam or flavour != "smth"):
                 masks.append(tmask)
     if write_files:
         if flavour == "smth":                                       # smth:307-313

@@ -1,8 +1,12 @@
 """Drop-in for the saliency-path functions of video_features_pytorch/visualisation.py
 (SURVEY 8f N3): `create_image_arrays`, `vizualize_results_on_gradcam`,
 `find_temp_mask_red_dots`, `vizualize_results` -- same names, arguments, return values and
-side effects (the caller's mask is snapped IN PLACE by the dot row, visualisation.py:77-81),
-with the pixel work in csrc/viz.hip.
+side effects, with the pixel work in csrc/viz.hip.  Who sees the 0/1 snap of the dot row
+(visualisation.py:77-81): `find_temp_mask_red_dots` snaps the tensor it is GIVEN, in place;
+`vizualize_results_on_gradcam` first rebinds `mask = mask.detach().cpu()` (:39), which for the
+drivers' CUDA masks (smth:216) is a COPY -- so the snap lands on that host copy (and in the
+MASKVALS file), never on the caller's tensor.  This module only takes GPU masks, hence the
+caller's mask is always left as it was.
 
 The reference's two undefined names are resolved the obvious way: `perturb_sequence`
 (visualisation.py:115) is `mask.perturb_sequence`, `args.subDir` (:10) becomes the
@@ -69,17 +73,20 @@ def _save_pngs(strip_bgr, rootDir, case):
 def vizualize_results_on_gradcam(gradCamImage, mask, rootDir, case="0", roundUpMask=True, imageWidth=224,
                                  imageHeight=224):
     """visualisation.py:35-64.  gradCamImage [3,T,H,3W] uint8 (BGR planes; numpy, or a CUDA tensor) is
-    modified in place like the reference's array; `mask` [T] on the GPU is snapped in place."""
+    modified in place like the reference's array.  `mask` [T] on the GPU is NOT modified: the reference
+    snaps its host copy (`mask.detach().cpu()`, :39), which is what the dots and the MASKVALS file show."""
     L.require_gpu(mask)
     if not os.path.exists(rootDir):
         os.makedirs(rootDir)
-    find_temp_mask_red_dots(imageWidth, imageHeight, mask, roundUpMask)          # snaps `mask`
+    dev = mask.device
+    mask = mask.detach().cpu().clone()                                           # :39 (a copy for a CUDA tensor)
+    find_temp_mask_red_dots(imageWidth, imageHeight, mask, roundUpMask)          # snaps the host copy
     is_np = isinstance(gradCamImage, np.ndarray)
-    planes = torch.from_numpy(gradCamImage).to(mask.device) if is_np else gradCamImage
+    planes = torch.from_numpy(gradCamImage).to(dev) if is_np else gradCamImage
     strip = planes.permute(1, 2, 3, 0).contiguous()                              # [T,H,3W,3]
     T, H, W3 = strip.shape[:3]
-    m = L.f32c(mask.detach())
-    with torch.cuda.device(mask.device):
+    m = L.f32c(mask.to(dev))
+    with torch.cuda.device(dev):
         L.check(L.lib().ivf_viz_dots(L.ptr(strip), L.ptr(m), T, H, W3, int(imageWidth), int(imageHeight), L.stream()))
     host = strip.cpu().numpy()
     if is_np:
@@ -88,14 +95,14 @@ def vizualize_results_on_gradcam(gradCamImage, mask, rootDir, case="0", roundUpM
         gradCamImage.copy_(strip.permute(3, 0, 1, 2))
     _save_pngs(host, rootDir, case)
     with open(os.path.join(rootDir, "MASKVALScase" + case + ".txt"), "w+") as f:
-        f.write(str(mask.detach().cpu()))
+        f.write(str(mask))
     return gradCamImage
 
 
 def create_image_arrays(input_sequence, gradcamMask, timeMask, intraBidx, temporalMaskType, output_folder, targTag,
                         RESIZE_FLAG, RESIZE_SIZE_WIDTH, RESIZE_SIZE_HEIGHT):
     """visualisation.py:96-130.  input_sequence [B,3,T,H,W] float 0..255 on the GPU, gradcamMask [T,H,W]
-    float32 (numpy or tensor), timeMask [T] on the GPU (snapped in place by the dot row).  Writes
+    float32 (numpy or tensor), timeMask [T] on the GPU (left unchanged: the dot row snaps a host copy).  Writes
     img%02d.jpg, mygif.gif, case<type><tag>_<i>.png and MASKVALScase<type><tag>.txt into output_folder and
     returns the [3,T,H,3W] uint8 array (BGR planes, dots included)."""
     from PIL import Image
@@ -110,8 +117,7 @@ def create_image_arrays(input_sequence, gradcamMask, timeMask, intraBidx, tempor
     cam = L.f32c(torch.as_tensor(gradcamMask).to(dev))
     if tuple(cam.shape) != (T, H, W):
         raise L.IvfError(f"gradcamMask must be [{T},{H},{W}], got {tuple(cam.shape)}")
-    # the third panel: the clip perturbed with the SNAPPED mask (a clone: this call does not snap the
-    # caller's mask, the dot row below does), visualisation.py:115-117
+    # the third panel: the clip perturbed with the SNAPPED mask (snap_values on a clone), visualisation.py:115-117
     pert = L.f32c(_mask.perturb_sequence(input_sequence, timeMask.detach().clone(),
                                          perturbation_type=temporalMaskType, snap_values=True)[intraBidx])
     strip = torch.empty(T, H, 3 * W, 3, dtype=torch.uint8, device=dev)

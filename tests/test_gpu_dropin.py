@@ -101,15 +101,17 @@ def test_find_masks_records(model, tmp_path, monkeypatch):
     assert tm[0]['original_score_guess'] == 0          # smth:218 casts the probability with int()
     files = [str(p) for p in (tmp_path / "cam_saved_images").rglob("*.txt")]
     assert any("ClassScoreFreezecase40" in f for f in files) and any("ClassScoreReversecase41" in f for f in files)
-    # batched per-clip search == one-clip-at-a-time search, bit for bit (rows independent)
+    # batched per-clip search == one-clip-at-a-time search, bit for bit (rows independent); without Grad-CAM the
+    # smth driver returns no masks (smth:296-303 appends inside `if doGradCam and runTempMask`)
     loader1 = ivf_find_masks.SyntheticLoader(1, 1, (3, 16, 224, 224), 174, first_id=41)
     m1 = drv.find_masks(loader1, model, {"batch_size": 1, "gradCamType": "guessed"}, 0.01, 0.02, 5, "central",
                         "freeze", classOI=None, doGradCam=False, runTempMask=True, verbose=False)
-    assert np.array_equal(m1[0].cpu().numpy(), tm[1]['time_mask'])
-    # with Grad-CAM on, the visualisation's dot row has snapped the returned masks in place
-    # (visualisation.py:77-81 via smth:296-303); the pickled time_mask keeps the continuous values
-    assert set(masks[1].unique().tolist()) <= {0.0, 1.0}
-    assert torch.equal(masks[1].cpu(), (torch.from_numpy(tm[1]['time_mask']) > 0.5).float())
+    assert m1 == []
+    assert np.array_equal(ivf_find_masks.find_masks_impl.last_results[0][0]['time_mask'], tm[1]['time_mask'])
+    # the returned masks are the sigmoid values: the visualisation's dot row snaps a host copy of the CUDA
+    # time_mask (visualisation.py:39,77-81), never the caller's tensor
+    assert np.array_equal(masks[1].cpu().numpy(), tm[1]['time_mask'])
+    assert not set(masks[1].unique().tolist()) <= {0.0, 1.0}
     pngs = [str(p) for p in (tmp_path / "cam_saved_images").rglob("*.png")]
     assert any("casefreeze40_15.png" in f for f in pngs) and any("casereverse41_0.png" in f for f in pngs)
     assert len(list((tmp_path / "cam_saved_images").rglob("mygif.gif"))) == 2
@@ -193,6 +195,14 @@ def test_kth_driver_find_masks(backbone, tmp_path, monkeypatch):
     gc = pickle.load(open(tmp_path / "results" / "I3d_KTH_allGradCamResults_original_run0.p", "rb"))
     assert len(tm) == 2 and tm[0]['time_mask'].shape == (32,) and tm[0]['video_id'] == "7"
     assert isinstance(tm[0]['original_score_guess'], float) and tm[0]['original_score_guess'] > 0   # no int() cast (KTH:274)
+    # KTH:360-367: the masks come back unsnapped, and the PerturbImgs PNGs carry the SOFT mask value in the
+    # top-left 10 x 10 square of the red channel (visualisation.py:20-25)
+    assert np.array_equal(masks[0].cpu().numpy(), tm[0]['time_mask'])
+    from PIL import Image
+    png = next(p for p in (tmp_path / "cam_saved_images").rglob("case7pert3.png"))
+    px = np.asarray(Image.open(png))
+    assert px.shape == (120, 160, 3) and (px[:10, :10, 0] == np.uint8(np.float32(tm[0]['time_mask'][3]) * 255)).all()
+    assert (px[:10, :10, 1:] == 0).all()
     if backbone == "i3d":
         assert len(gc) == 2 and gc[0]['GCHeatMap'].shape == (32, 120, 160) and gc[0]['GCHeatMap'].dtype == np.float32
     else:
