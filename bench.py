@@ -14,12 +14,19 @@ per-clip records inside the timed region.
 ranks itself (child `python -m torch.distributed.run ...`, before this process
 touches the GPU) and exits with the child's code.
 
+The headline arithmetic is `bf16x6`: every fp32 operand split into three bf16 planes (all 24
+significand bits), six MFMA passes per k-step, fp32 accumulate, fp32 storage -- the reference's fp32
+arithmetic (logits within 1e-6 of the exact-fp32 MFMA chain) on the bf16 matrix cores.
+
 Prints ONE JSON line on rank 0.  At N=1 the same line also carries
-  * `secondary.fp32_exact`: the same search in the reference's own arithmetic
-    (exact-fp32 MFMA, `--math fp32`), a few short steps;
+  * `secondary.s32` / `secondary.s32_bf16act`: BASELINE configs[4], 32-frame clips, in the headline
+    arithmetic and in its stated form (bf16 activation storage, 2 MFMA passes);
+  * `secondary.bf16x3`: the 16-bit-significand split (3 passes; within north_star's 1e-3, not fp32);
+  * `secondary.fp32_mfma`: the native fp32 MFMA (v_mfma_f32_32x32x2_f32) for reference;
   * `secondary.convlstm`: BASELINE configs[3], CLSTM_4 on [B,1,32,120,160], N=100;
   * `cpu_baseline`: the CPU oracle on the host cores (port), plus the
-    reference-literal cost line (B=16 forward per iteration + weight gradients).
+    reference-literal cost line (B=16 forward per iteration + weight gradients);
+  * `summary`: the headline figures of every block again, compact, as the LAST key of the line.
 """
 import argparse
 import ctypes
@@ -35,13 +42,26 @@ sys.path.insert(0, os.path.join(ROOT, "interpreting-video-features_amd"))
 sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks, HBM3E peak
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+PEAK_FP32_MFMA, PEAK_BF16_MFMA = 157.3, 2500.0
 PEAK_HBM_GBS = 8000.0
-PEAK_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-             "bf16x3": "bf16 dense MFMA (v_mfma_f32_32x32x16_bf16); every algorithmic FLOP costs 3 MFMA FLOPs "
-                       "in the split-bf16 mode, so the fp32-equivalent ceiling is 833 TFLOP/s"}
+# mode -> (dtype string of the JSON line, dense MFMA peak for THAT dtype, MFMA passes per algorithmic FLOP)
+MODES = {
+    "fp32": ("f32", PEAK_FP32_MFMA, 1, "fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains"),
+    "bf16x6": ("f32 (each operand as 3 bf16 planes = 24 significand bits, 6 MFMA passes, f32 accumulate, f32 storage)",
+               PEAK_FP32_MFMA, 6,
+               "results are fp32-class (logits within 1e-6 of the fp32 MFMA chain), so `peak` is the dense fp32 MFMA "
+               "peak; the instructions are v_mfma_f32_32x32x16_bf16, 6 MFMA FLOPs per algorithmic FLOP: the ceiling of "
+               "this form is 2500/6 = 417 TFLOP/s, see `matrix_pipe`"),
+    "bf16x3": ("bf16x3 (each operand as 2 bf16 planes = 16 significand bits, 3 MFMA passes, f32 accumulate, f32 storage)",
+               PEAK_BF16_MFMA, 3,
+               "bf16 dense MFMA; every algorithmic FLOP costs 3 MFMA FLOPs, so the ceiling of this form is 833 TFLOP/s"),
+    "bf16act": ("bf16 activations/gradients in HBM (RNE), weights as 2 bf16 planes, 2 MFMA passes, f32 accumulate",
+                PEAK_BF16_MFMA, 2,
+                "bf16 dense MFMA; every algorithmic FLOP costs 2 MFMA FLOPs, so the ceiling of this form is 1250 TFLOP/s"),
+}
+HEADLINE_MATH = "bf16x6"
 NCLASS = 96   # IVF_PROFILE_CLASSES
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
 
 
 def parse_args():
@@ -49,17 +69,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (searched together)")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (searched together)")
     ap.add_argument("--iters", type=int, default=300, help="Adam iterations per search (reference N=300)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the fp32_exact and convlstm blocks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (other arithmetic modes, S32, ConvLSTM)")
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     ap.add_argument("--tuning", default=None,
                     help="JSON file with a per-layer kernel choice: loaded instead of autotuning when it exists and fits "
                          "this plan, written after autotuning otherwise (profiling runs: no tuner launches in the trace)")
-    ap.add_argument("--math", choices=["fp32", "bf16x3"], default=None,
-                    help="arithmetic of the Unit3D convolutions (default: ivf_engine.DEFAULT_MATH)")
+    ap.add_argument("--math", choices=sorted(MODES), default=HEADLINE_MATH,
+                    help="arithmetic of the Unit3D convolutions of the headline block")
     return ap.parse_args()
 
 
@@ -191,7 +211,7 @@ def collect_roofline(L, eng, B):
         return None
     name = lambda v: lib.ivf_profile_class_name(v).decode() or f"class{v}"
     math = eng.math
-    peak = PEAK_TFLOPS[math]
+    _, peak, passes, peak_note = MODES[math]
     dom = int(np.argmax([s_ms[i] for i in range(ns)]))
     buf = ctypes.create_string_buffer(64)
     L.check(lib.ivf_i3d_site_name(eng._h, dom, buf))
@@ -205,14 +225,17 @@ def collect_roofline(L, eng, B):
     shares = {name(i): round(ms[i] / tot_ms, 3) for i in range(NCLASS) if launches[i] > 0}
     # HBM bytes per launch of THAT site from this round's PMC passes (profiles/), taken on the same batch
     # size and the same kernel template; otherwise null
+    # keyed by launch site, arithmetic mode, batch and frames; the kernel template the PMC run had tuned for that site is
+    # quoted beside it (the tuner may pick another tile on another box: the compulsory bytes of the site do not change)
     traffic, src = None, None
     try:
         pm = json.load(open(PMC_FILE))
         ent = pm["sites"].get(site)
-        if ent and pm.get("batch") == B and ent["kernel"] == name(v).replace(" ", ""):
+        if ent and pm.get("batch") == B and pm.get("math") == math and pm.get("frames", 16) == eng.clip_shape[1]:
             traffic = ent["hbm_bytes_per_launch"]
-            src = ("profiles/r02_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                   "FETCH doubled per the gfx950 rule; same launch site, kernel template and batch as this run)")
+            src = (f"profiles/{os.path.basename(PMC_FILE)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH "
+                   f"doubled per the gfx950 rule; same launch site, arithmetic and batch as this run; kernel there: "
+                   f"{ent['kernel']})")
     except (OSError, ValueError, KeyError):
         pass
     return {
@@ -223,11 +246,17 @@ def collect_roofline(L, eng, B):
         # rocprofv3 --stats averages per kernel NAME, i.e. over every site the template serves: the figure to
         # compare with profiles/r02_bench_kernel_stats.csv
         "kernel_name_avg_launch_ms": round(ms[v] / launches[v], 4), "kernel_name_sampled_launches": int(launches[v]),
-        "mfma_passes_per_algorithmic_flop": 3 if math == "bf16x3" else 1,
+        "mfma_passes_per_algorithmic_flop": passes,
+        # what the matrix pipe itself is doing: MFMA FLOPs issued (algorithmic x passes) against the dense peak of the
+        # MFMA instruction the kernel issues
+        "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "peak": PEAK_BF16_MFMA,
+                         "frac": round(achieved * passes / PEAK_BF16_MFMA, 4)} if math != "fp32" else
+                        {"instruction": "v_mfma_f32_32x32x2_f32", "peak": PEAK_FP32_MFMA,
+                         "frac": round(achieved / PEAK_FP32_MFMA, 4)}),
         "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                              "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              "share_of_sampled_conv_time": shares},
-        "peak_dtype": PEAK_NOTE[math],
+        "peak_dtype": peak_note,
     }
 
 
@@ -244,7 +273,9 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
     if tuning_file and os.path.exists(tuning_file):
         try:
             doc = json.load(open(tuning_file))
-            if doc.get("batch") == B and doc.get("math") == eng.math and doc.get("frames") == T:
+            # (lib_version: the variant ids of a saved choice are only meaningful for the variant table that made them)
+            if doc.get("batch") == B and doc.get("math") == eng.math and doc.get("frames") == T and \
+                    doc.get("lib_version") == L.lib().ivf_version():
                 saved = doc["variants"]
         except (OSError, ValueError, KeyError):
             saved = None
@@ -257,7 +288,8 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
             saved = None
     if tuning_file and saved is None and rank == 0:
         try:
-            json.dump({"batch": B, "math": eng.math, "frames": T, "variants": eng.get_tuning()}, open(tuning_file, "w"))
+            json.dump({"batch": B, "math": eng.math, "frames": T, "lib_version": L.lib().ivf_version(),
+                       "variants": eng.get_tuning()}, open(tuning_file, "w"))
         except OSError:
             pass
     if dist is not None:
@@ -376,41 +408,61 @@ def main():
 
     lam1, lam2 = 0.01, 0.02   # FindMasksComparison_I3D_smth.py:106-113
     T, B = args.frames, args.batch
-    elapsed, roofline, math = timed_i3d(torch, dist, dev, rank, world, args.math, B, T, args.iters, args.steps,
-                                        args.warmup, lam1, lam2, tuning_file=args.tuning)
+    cfg_name = {16: "BASELINE configs[1]", 32: "BASELINE configs[4] geometry"}.get(T, "")
+
+    def i3d_block(math, frames, batch, steps, warmup, what, tuning=None, dist_=None, rank_=0, world_=1):
+        """One timed block of the full I3D search -> the bench line's fields for it."""
+        el, roof, m = timed_i3d(torch, dist_, dev, rank_, world_, math, batch, frames, args.iters, steps, warmup, lam1,
+                                lam2, tuning_file=tuning)
+        return {
+            "metric": f"clips/sec full mask-search (I3D, {frames}f, {args.iters} iters)",
+            "value": round(world_ * batch * steps / el, 4), "unit": "clips/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(el / steps * 1e3, 2), "dtype": MODES[m][0],
+            "config": {"workload": what, "clips_per_gpu_per_step": batch, "iters": args.iters, "frames": frames,
+                       "math": m},
+            "roofline": roof}
+
+    blk = i3d_block(args.math, T, B, args.steps, args.warmup,
+                    f"I3D perturbation mask search, {args.iters} iters, synthetic clips [{B},3,{T},224,224] per GPU per step "
+                    f"({cfg_name}); init_mask + search + reverse score + Grad-CAM",
+                    tuning=args.tuning, dist_=dist, rank_=rank, world_=world)
     if rank == 0:
-        clips = world * B * args.steps
         out = {
-            "metric": "clips/sec full mask-search (I3D, 16f, 300 iters)",
-            "value": round(clips / elapsed, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "metric": "clips/sec full mask-search (I3D, 16f, 300 iters)" if T == 16 else blk["metric"],
+            "value": blk["value"], "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": blk["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if math == "fp32" else "bf16x3 (split-bf16 MFMA, f32 accumulate, f32 storage)",
-            "data": "synthetic",
-            "config": {"workload": f"I3D perturbation mask search, {args.iters} iters, synthetic clips "
-                                   f"[{B},3,{T},224,224] per GPU per step (BASELINE configs[1]); init_mask + "
-                                   f"search + reverse score + Grad-CAM",
-                       "clips_per_gpu_per_step": B, "iters": args.iters, "frames": T,
-                       "lam1": lam1, "lam2": lam2, "sharding": f"clip_id % {world}, one all_gather of records"},
-            "roofline": roofline,
+            "dtype": blk["dtype"], "data": "synthetic",
+            "config": dict(blk["config"], lam1=lam1, lam2=lam2, sharding=f"clip_id % {world}, one all_gather of records"),
+            "roofline": blk["roofline"],
         }
+        summary = {"headline": {"math": args.math, "clips_per_s": blk["value"],
+                                "roofline_frac": (blk["roofline"] or {}).get("frac"),
+                                "matrix_pipe_frac": ((blk["roofline"] or {}).get("matrix_pipe") or {}).get("frac")}}
         if world == 1 and not args.no_secondary:
             sec = {}
-            if math != "fp32":
-                # the reference's own arithmetic (stock fp32 Conv3d, I3D_doubled.py:83-118): exact-fp32 MFMA
-                fb, fs = 16, 2
-                el, roof, _ = timed_i3d(torch, None, dev, 0, 1, "fp32", fb, T, args.iters, fs, 1, lam1, lam2)
-                sec["fp32_exact"] = {
-                    "metric": out["metric"], "value": round(fb * fs / el, 4), "unit": "clips/s", "steps": fs,
-                    "warmup": 1, "ms_per_step": round(el / fs * 1e3, 2), "dtype": "f32",
-                    "config": {"workload": f"same search, [{fb},3,{T},224,224] per step, exact-fp32 MFMA "
-                                           f"(v_mfma_f32_32x32x2_f32)", "clips_per_gpu_per_step": fb,
-                               "iters": args.iters},
-                    "roofline": roof}
+            if T == 16:
+                # BASELINE configs[4]: 32-frame 224^2 clips, head window [4,7,7] (stride_mod_layers="none", SURVEY F13):
+                # in the headline arithmetic, and in the configuration's stated form (bf16 activation storage)
+                for key, m, sb, ss in (("s32", args.math, min(16, B), 1), ("s32_bf16act", "bf16act", min(16, B), 2)):
+                    sec[key] = i3d_block(m, 32, sb, ss, 1,
+                                         f"I3D mask search + Grad-CAM on 32-frame clips [{sb},3,32,224,224] per step, "
+                                         f"stride_mod_layers='none' (BASELINE configs[4]"
+                                         f"{'; bf16 activation / gradient storage, fp32 accumulate' if m == 'bf16act' else ''})")
+            for key, m, sb, ss in (("bf16x3", "bf16x3", B, 2), ("fp32_mfma", "fp32", min(16, B), 1)):
+                if m != args.math:
+                    sec[key] = i3d_block(m, T, sb, ss, 1, f"same search, [{sb},3,{T},224,224] per step, {MODES[m][3]}")
             sec["convlstm"] = convlstm_block(torch, dev)
             out["secondary"] = sec
+            for key, b_ in sec.items():
+                r = b_.get("roofline") or {}
+                summary[key] = {"clips_per_s": b_["value"], "roofline_frac": r.get("frac"), "bound": r.get("bound"),
+                                "math": b_["config"].get("math", "f32")}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_sample_iters, lam1, lam2, host_cores())
+            summary["cpu_baseline"] = {"clips_per_s": round(out["cpu_baseline"]["value"], 5),
+                                       "cores": out["cpu_baseline"]["cores"], "kind": out["cpu_baseline"]["kind"]}
+        out["summary"] = summary      # LAST key: the figures of every block inside the tail of the line
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:

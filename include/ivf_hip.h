@@ -118,12 +118,25 @@ int ivf_clip_ingest_u8(const unsigned char* frames, float* out, int B, int T, in
 /* ------------------------------------------------------------------ Unit3D */
 
 /* Arithmetic of the implicit-GEMM convolution:
- *  IVF_MATH_FP32   v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (157 TFLOP/s peak);
- *  IVF_MATH_BF16X3 every operand split x = hi + lo (two bf16), three
- *                  v_mfma_f32_32x32x16_bf16 per k-step (lo*hi + hi*lo + hi*hi), fp32
- *                  accumulate: ~2^-17 relative per product, 5.3x the fp32-MFMA rate. */
+ *  IVF_MATH_FP32    v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (157 TFLOP/s peak);
+ *  IVF_MATH_BF16X3  every operand split x = hi + lo (two bf16), three
+ *                   v_mfma_f32_32x32x16_bf16 per k-step (lo*hi + hi*lo + hi*hi), fp32
+ *                   accumulate: ~2^-17 relative per product, 5.3x the fp32-MFMA rate;
+ *  IVF_MATH_BF16X6  every operand split x = hi + mid + lo (three bf16 = all 24 bits of the fp32
+ *                   significand), six MFMAs per k-step (every term down to 2^-16 of the product), fp32
+ *                   accumulate: an fp32 product to ~2^-23 -- the reference's fp32 arithmetic on the bf16
+ *                   matrix cores, 2.65x the fp32-MFMA rate (ceiling 417 TFLOP/s);
+ *  IVF_MATH_BF16ACT activations AND gradients are stored as bf16 in HBM (round-to-nearest-even in the
+ *                   epilogues), weights stay split hi/lo, two MFMAs per k-step (a*lo + a*hi), fp32
+ *                   accumulate (BASELINE configs[4]: "bf16 activations").  In this mode every in / out /
+ *                   in2 / out2 / relu_mask pointer of ivf_conv3d addresses bf16 elements (same element
+ *                   offsets), with two exceptions at the ends of the network: a 4-channel-pixel strided
+ *                   convolution (IVF_CONV_PIX4, the stem) READS fp32 pixels, and a depth-to-space
+ *                   backward (d2s, the stem's input gradient) WRITES fp32. */
 #define IVF_MATH_FP32 0
 #define IVF_MATH_BF16X3 1
+#define IVF_MATH_BF16X6 2
+#define IVF_MATH_BF16ACT 3
 
 /* One convolution as implicit GEMM on the matrix cores.  Forward of Unit3D
  * (models/I3D_doubled.py:83-118: asymmetric zero pad + Conv3d + BN(eval) + ReLU) and,
@@ -141,7 +154,7 @@ typedef struct {
   int d2s;                     /* depth-to-space output: stride-2 backward-data */
   int dT, dH, dW, dC;          /* d2s: real output dims and channels written */
   int bsT, bsH, bsW;           /* d2s: block strides (forward strides, 1 or 2) */
-  int math;                    /* IVF_MATH_FP32 or IVF_MATH_BF16X3; must match the weight pack */
+  int math;                    /* IVF_MATH_*; must match the weight pack */
   int variant;                 /* IVF_CONV_AUTO, or a kernel variant id from ivf_conv3d_variants() */
   /* optional second input of a 1x1x1 conv: GEMM-K channels [K0, Cin) are read from in2 (same
    * positions; row length in2_ld, channel offset in2_coff), channels [0, K0) from `in` */
@@ -183,7 +196,8 @@ int ivf_bn_fold(const float* gamma, const float* beta, const float* mean, const 
                 float* scale, float* shift, int C, ivf_stream_t stream);
 
 /* Reference weight [Cout][Cin][kT][kH][kW] -> forward pack [Cout][taps*CinPad]
- * (fp32, or two bf16 planes hi/lo with rows padded to 8 for IVF_MATH_BF16X3);
+ * (fp32, or bf16 planes with rows padded to 8: hi/lo for IVF_MATH_BF16X3 and IVF_MATH_BF16ACT, hi/mid/lo for
+ * IVF_MATH_BF16X6);
  * w_packed holds ivf_conv3d_pack_fwd_elems() floats. */
 size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int math);
 int ivf_conv3d_pack_fwd(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad, int kT,
@@ -228,14 +242,17 @@ typedef struct {
    * When x is a ReLU output and the gradient is wanted below that ReLU, the backward then
    * needs no relu_mask: a cell with x <= 0 can only win a window whose maximum is <= 0. */
   int gate_nonpos;
+  /* storage of x / y / dy / dx / relu_mask: 0 = float, 1 = bf16 (IVF_MATH_BF16ACT plans; same element offsets).  The
+   * forward only selects, so it is exact in either storage; the backward sums in fp32 and rounds once on store. */
+  int act_bf16;
 } ivf_pool3d_desc;
 
 /* MaxPool3dSamePadding.forward, I3D_doubled.py:15-40; argmax [positions_out][C] uint8
  * (flat tap of the winner, first strict maximum, pad cells count as 0). */
-int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float* y, unsigned char* argmax,
+int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const void* x, void* y, unsigned char* argmax,
                       ivf_stream_t stream);
-int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, const unsigned char* argmax, float* dx,
-                      const float* relu_mask, int accumulate, ivf_stream_t stream);
+int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const void* dy, const unsigned char* argmax, void* dx,
+                      const void* relu_mask, int accumulate, ivf_stream_t stream);
 
 /* I3D head, I3D_doubled.py:360-380, for a pooling window covering the whole feature
  * map: feat [B,npos,C] -> pooled [B,C] (optional) -> logits [B,K] -> probs [B,K]
@@ -250,12 +267,22 @@ int ivf_head_fwd(const float* feat, const float* w, const float* bias, float* po
 int ivf_head_bwd(const float* feat, const float* w, const float* probs, const int* target,
                  const float* dout, float* score, float* dpooled, float* dfeat, int B, int npos, int C,
                  int K, int softmax, int gate_relu, ivf_stream_t stream);
+/* The same two with the feature map (and dfeat) stored as bf16 (IVF_MATH_BF16ACT plans); pooled / logits /
+ * probs / score / dpooled stay fp32. */
+int ivf_head_fwd_bf16(const void* feat, const float* w, const float* bias, float* pooled, float* logits,
+                      float* probs, int B, int npos, int C, int K, int softmax, ivf_stream_t stream);
+int ivf_head_bwd_bf16(const void* feat, const float* w, const float* probs, const int* target,
+                      const float* dout, float* score, float* dpooled, void* dfeat, int B, int npos, int C,
+                      int K, int softmax, int gate_relu, ivf_stream_t stream);
 
 /* ------------------------------------------------------------------ Grad-CAM */
 
 /* grad_cam_videos.py:98-110: weights[b,k] = mean_pos grad; cam[b,pos] = relu(sum_k w*feat). */
 int ivf_gradcam_reduce(const float* feat, const float* grad, float* weights, float* cam, int B, int npos,
                        int C, ivf_stream_t stream);
+/* feat and grad stored as bf16 (IVF_MATH_BF16ACT plans); weights and cam fp32. */
+int ivf_gradcam_reduce_bf16(const void* feat, const void* grad, float* weights, float* cam, int B, int npos,
+                            int C, ivf_stream_t stream);
 
 /* grad_cam_videos.py:113-138: per temporal slice bilinear resize (sh,sw)->(H,W)
  * (OpenCV INTER_LINEAR rule), repeat `step` frames, min/max normalise per slice block
@@ -275,7 +302,8 @@ typedef struct {
   int pool5a_stride_t;   /* MaxPool3d_5a_2x2 */
   int head_kt, head_kh, head_kw; /* AvgPool3d window: (2,7,7) / (finalTimeLength,4,5) */
   int softmax;           /* Model(softMax=...) */
-  int math;              /* IVF_MATH_FP32 or IVF_MATH_BF16X3 for every Unit3D convolution */
+  int math;              /* IVF_MATH_* for every Unit3D convolution (IVF_MATH_BF16ACT also selects bf16 storage of
+                            every activation / gradient buffer of the plan except the clip and its gradient) */
 } ivf_i3d_config;
 
 typedef struct ivf_i3d ivf_i3d_t;
@@ -323,6 +351,9 @@ float* ivf_i3d_input_grad_buffer(ivf_i3d_t* net);
  * channels-last [b,T,H,W,ld]; returns IVF_ERR_BAD_ARG for an unknown name. */
 int ivf_i3d_endpoint(const ivf_i3d_t* net, const char* name, float** ptr, int* T, int* H, int* W, int* C,
                      int* ld);
+/* Bytes per stored element of those endpoints (and of every other activation / gradient buffer except the clip and
+ * its gradient): 4 (float), or 2 (bf16) in an IVF_MATH_BF16ACT plan -- *ptr then addresses bf16 elements. */
+int ivf_i3d_act_elem_bytes(const ivf_i3d_t* net);
 
 /* The hot loop, smth:193-214, for b clips with per-clip masks, entirely on the
  * device: N iterations of sigmoid/L1/TV -> freeze -> forward -> score -> backward

@@ -162,33 +162,35 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvKArgs a) {
     __syncthreads();
   }
 
-  conv_epilogue<TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
-                        n0 + wn * (BN / WN), li, lh);
+  conv_epilogue<AM_X3, TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
+                               n0 + wn * (BN / WN), li, lh);   // (AM_X3: fp32 storage)
 }
 
-// ------------------------------------------------------------------ split-bf16 (3-pass) variant
+// ------------------------------------------------------------------ split-bf16 variants
 // fp32-level accuracy on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
 // a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (the dropped lo*lo term is 2^-18 relative), each
 // product exact in fp32, fp32 accumulation in the MFMA.  3 x v_mfma_f32_32x32x16_bf16 per 16-deep
 // k-step = 96 cycles against 512 for the fp32 MFMA form.  Activations stay fp32 in HBM and are
 // split while they are staged into LDS; weights are pre-split by the pack kernels.
+// AM (conv_common.h) selects the operand planes: AM_X3 as above, AM_X6 the 3-way split with six passes (fp32-class
+// products), AM_BF16 bf16 activations staged as they are with two passes and bf16 stores.
 // PW = pointwise (1x1x1, stride 1, no padding: every 1x1x1 unit of the Inception modules and their fused
 // backward GEMM): A is a plain [M][K] matrix, so the per-chunk tap decode (three integer divisions and the bounds
 // tests per thread: 12-41 vector instructions per MFMA, measured) drops out; rows are addressed through two
-// pointers computed once, loads are unconditional (rows past M and the k tail are clamped: they meet zero weights
+// offsets computed once, loads are unconditional (rows past M and the k tail are clamped: they meet zero weights
 // or land in rows nobody stores).
-template <int BM, int BN, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
+template <int AM, int BM, int BN, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv3d_igemm_bf16_kernel(ConvKArgs a) {
+  constexpr int NPA = OpPlanes<AM>::A, NPB = OpPlanes<AM>::B;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int AROWS = BM / 32;
   constexpr int BROWS = (BN + 63) / 64;   // weight rows each thread stages per plane (8 bf16 per load)
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile");
+  static_assert((NPA * BM + NPB * BN) * LDS_ROW_BF * 2 <= 64 * 1024, "static LDS");
 
-  __shared__ __attribute__((aligned(16))) unsigned short a_hi[BM * LDS_ROW_BF];
-  __shared__ __attribute__((aligned(16))) unsigned short a_lo[BM * LDS_ROW_BF];
-  __shared__ __attribute__((aligned(16))) unsigned short b_hi[BN * LDS_ROW_BF];
-  __shared__ __attribute__((aligned(16))) unsigned short b_lo[BN * LDS_ROW_BF];
+  __shared__ __attribute__((aligned(16))) unsigned short a_pl[NPA][BM * LDS_ROW_BF];
+  __shared__ __attribute__((aligned(16))) unsigned short b_pl[NPB][BN * LDS_ROW_BF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -202,21 +204,20 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   const int m0 = mt * BM;
   const int n0 = nt * BN;
 
-  const int g = tid & 7;            // A: float4 group of the 32-wide chunk
+  const int g = tid & 7;            // A: 4-channel group of the 32-wide chunk
   const int r0 = perm8(tid >> 3);   //    rows r0 + 32 j (perm8: conflict-free LDS staging writes)
   const int g2 = tid & 3;           // B: group of 8 bf16
   const int q0 = perm8(tid >> 2);   //    rows q0 + 64 j
 
   int a_base[AROWS], a_t0[AROWS], a_h0[AROWS], a_w0[AROWS];
-  const float* a_p1[AROWS];
-  const float* a_p2[AROWS];
+  size_t a_o1[AROWS], a_o2[AROWS];   // PW: element offsets of the row in `in` / `in2` (the latter minus K0)
 #pragma unroll
   for (int j = 0; j < AROWS; ++j) {
     int m = m0 + r0 + 32 * j;
     if constexpr (PW) {
       const size_t mc = (size_t)min(m, a.M - 1);
-      a_p1[j] = a.in + mc * a.in_ld + a.in_coff;
-      a_p2[j] = a.in2 ? a.in2 + mc * a.in2_ld + a.in2_coff - a.K0 : a_p1[j];
+      a_o1[j] = mc * a.in_ld + a.in_coff;
+      a_o2[j] = a.in2 ? mc * a.in2_ld + a.in2_coff - a.K0 : a_o1[j];
       a_base[j] = a_t0[j] = a_h0[j] = a_w0[j] = 0;
     } else if (m < a.M) {
       int wo = m % a.Wo;
@@ -229,8 +230,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
       a_h0[j] = ho * a.sH - a.pH;
       a_w0[j] = wo * a.sW - a.pW;
       a_base[j] = b * a.Ti;
+      a_o1[j] = a_o2[j] = 0;
     } else {
       a_t0[j] = -100000; a_h0[j] = 0; a_w0[j] = 0; a_base[j] = 0;
+      a_o1[j] = a_o2[j] = 0;
     }
   }
   const unsigned short* wrow[BROWS];
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   }
 
   float4 ra[AROWS];
-  uint4 rbh[BROWS], rbl[BROWS];
+  uint4 rb[NPB][BROWS];
   const int khw = a.kH * a.kW;
 
   auto load_chunk = [&](int k0) {
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
       const int kk = min(k0 + 4 * g, a.K - 4);
       const bool second = a.in2 && kk >= a.K0;
 #pragma unroll
-      for (int j = 0; j < AROWS; ++j) ra[j] = *reinterpret_cast<const float4*>((second ? a_p2[j] : a_p1[j]) + kk);
+      for (int j = 0; j < AROWS; ++j)
+        ra[j] = second ? load_act4<AM>(a.in2, a_o2[j] + kk) : load_act4<AM>(a.in, a_o1[j] + kk);
     } else {
       int kk = k0 + 4 * g;
       bool kvalid = kk < a.K;
@@ -267,9 +271,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
           size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
-          v = (a.in2 && kk >= a.K0)
-                  ? *reinterpret_cast<const float4*>(a.in2 + pos * a.in2_ld + a.in2_coff + (kk - a.K0))
-                  : *reinterpret_cast<const float4*>(a.in + pos * a.in_ld + a.in_coff + ci);
+          v = (a.in2 && kk >= a.K0) ? load_act4<AM>(a.in2, pos * a.in2_ld + a.in2_coff + (kk - a.K0))
+                                    : load_act4<AM>(a.in, pos * a.in_ld + a.in_coff + ci);
         }
         ra[j] = v;
       }
@@ -277,13 +280,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
     int kb = k0 + 8 * g2;
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
-      uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-      if (kb < a.ldw && wrow[j]) {
-        h = *reinterpret_cast<const uint4*>(wrow[j] + kb);
-        l = *reinterpret_cast<const uint4*>(wrow[j] + a.w_lo_off + kb);
+#pragma unroll
+      for (int pl = 0; pl < NPB; ++pl) {
+        uint4 h = make_uint4(0u, 0u, 0u, 0u);
+        if (kb < a.ldw && wrow[j]) h = *reinterpret_cast<const uint4*>(wrow[j] + pl * a.w_lo_off + kb);
+        rb[pl][j] = h;
       }
-      rbh[j] = h;
-      rbl[j] = l;
     }
   };
 
@@ -299,17 +301,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
   load_chunk(0);
   for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) {
-      uint2 h, l;
-      split4(ra[j], &h, &l);
-      *reinterpret_cast<uint2*>(&a_hi[(r0 + 32 * j) * LDS_ROW_BF + 4 * g]) = h;
-      *reinterpret_cast<uint2*>(&a_lo[(r0 + 32 * j) * LDS_ROW_BF + 4 * g]) = l;
-    }
+    for (int j = 0; j < AROWS; ++j)
+      stage_planes<AM>(reinterpret_cast<unsigned char*>(&a_pl[0][(r0 + 32 * j) * LDS_ROW_BF + 4 * g]),
+                       sizeof(a_pl[0]), ra[j]);
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       if (q0 + 64 * j < BN) {
-        *reinterpret_cast<uint4*>(&b_hi[(q0 + 64 * j) * LDS_ROW_BF + 8 * g2]) = rbh[j];
-        *reinterpret_cast<uint4*>(&b_lo[(q0 + 64 * j) * LDS_ROW_BF + 8 * g2]) = rbl[j];
+#pragma unroll
+        for (int pl = 0; pl < NPB; ++pl) *reinterpret_cast<uint4*>(&b_pl[pl][(q0 + 64 * j) * LDS_ROW_BF + 8 * g2]) = rb[pl][j];
       }
     }
     __syncthreads();
@@ -317,32 +316,28 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(ConvKArgs a) {
 
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+      bf16x8 fa[TM][NPA], fb[TN][NPB];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         int off = (wm * (BM / WM) + i * 32 + li) * LDS_ROW_BF + ks * 16 + 8 * lh;
-        fah[i] = *reinterpret_cast<const bf16x8*>(&a_hi[off]);
-        fal[i] = *reinterpret_cast<const bf16x8*>(&a_lo[off]);
+#pragma unroll
+        for (int pl = 0; pl < NPA; ++pl) fa[i][pl] = *reinterpret_cast<const bf16x8*>(&a_pl[pl][off]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         int off = (wn * (BN / WN) + j * 32 + li) * LDS_ROW_BF + ks * 16 + 8 * lh;
-        fbh[j] = *reinterpret_cast<const bf16x8*>(&b_hi[off]);
-        fbl[j] = *reinterpret_cast<const bf16x8*>(&b_lo[off]);
+#pragma unroll
+        for (int pl = 0; pl < NPB; ++pl) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&b_pl[pl][off]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j) mma_planes<AM>(fa[i], fb[j], acc[i][j]);
     }
     __syncthreads();
   }
-  conv_epilogue<TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
-                        n0 + wn * (BN / WN), li, lh);
+  conv_epilogue<AM, TM, TN>(a, acc, [&](int row) { int m = m0 + row; return m < a.M ? m : -1; }, wm * (BM / WM),
+                            n0 + wn * (BN / WN), li, lh);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -356,10 +351,12 @@ __device__ __forceinline__ void store_packed(float* out, int math, size_t row, i
   } else {
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
     unsigned h = pk_bf16(v, 0.f) & 0xffffu;
-    float hf = __uint_as_float(h << 16);
-    unsigned l = pk_bf16(v - hf, 0.f) & 0xffffu;
+    const float r1 = v - __uint_as_float(h << 16);
+    unsigned l = pk_bf16(r1, 0.f) & 0xffffu;
     o[row * ldw + k] = (unsigned short)h;
-    o[rows * (size_t)ldw + row * ldw + k] = (unsigned short)l;
+    o[rows * (size_t)ldw + row * ldw + k] = (unsigned short)l;   // lo (2 planes) or mid (3 planes)
+    if (math == IVF_MATH_BF16X6)
+      o[2 * rows * (size_t)ldw + row * ldw + k] = (unsigned short)(pk_bf16(r1 - __uint_as_float(l << 16), 0.f) & 0xffffu);
   }
 }
 
@@ -474,37 +471,51 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   }
 }
 
+template <int AM, int BM, int BN, int WM, int WN>
+static void launch_bf16(ConvKArgs& a, bool pw, dim3 grid, hipStream_t s) {
+  if (pw)
+    hipLaunchKernelGGL((conv3d_igemm_bf16_kernel<AM, BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv3d_igemm_bf16_kernel<AM, BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = cdiv(a.Cout, BN);
   dim3 grid(a.mtiles * a.ntiles);
-  // profiler class: 1..3 fp32 tiles, 4..6 split-bf16 tiles, 7..9 the wide split-bf16 tiles
+  // profiler class: 1..3 fp32 tiles, 4..6 split-bf16 tiles, 7..9 the wide split-bf16 tiles, 10..11 the small ones
   const int cls = BM == 64 ? (BN == 64 ? 10 : 11)
                   : BN > 128 ? (BN == 256 ? 7 : (BN == 192 ? 8 : 9))
                              : IVF_CONV_IGEMM_BASE + (BN == 128 ? 0 : (BN == 64 ? 1 : 2)) + (math ? 3 : 0);
-  if constexpr (BN > 128 || BM == 64) {
-    if (math == 0) {
-      set_error("conv3d: wide implicit-GEMM tiles exist for split-bf16 only");
-      return IVF_ERR_UNSUPPORTED;
-    }
+  constexpr bool wide = BN > 128 || BM == 64;          // split-bf16 only
+  constexpr bool fits_x6 = (3 * BM + 3 * BN) * LDS_ROW_BF * 2 <= 64 * 1024;
+  if (wide && math == IVF_MATH_FP32) {
+    set_error("conv3d: wide implicit-GEMM tiles exist for the split-bf16 modes only");
+    return IVF_ERR_UNSUPPORTED;
   }
-  prof_name(cls, "%s<%d,%d,%d,%d>", math ? "conv3d_igemm_bf16x3_kernel" : "conv3d_igemm_kernel", BM, BN, WM, WN);
+  if (!fits_x6 && math == IVF_MATH_BF16X6) {
+    set_error("conv3d: this implicit-GEMM tile does not fit the LDS with three operand planes");
+    return IVF_ERR_UNSUPPORTED;
+  }
+  if (math == IVF_MATH_FP32)
+    prof_name(cls, "conv3d_igemm_kernel<%d,%d,%d,%d>", BM, BN, WM, WN);
   // a plain GEMM over the pixels: no taps, no strides, no padding
   const bool pw = a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 && a.pW == 0 &&
                   a.To == a.Ti && a.Ho == a.Hi && a.Wo == a.Wi && a.K >= 4 && a.K % 4 == 0 && !a.d2s;
+  if (math != IVF_MATH_FP32)
+    prof_name(cls, "conv3d_igemm_bf16_kernel<%d,%d,%d,%d,%d,%s>", math == IVF_MATH_BF16X6 ? AM_X6 : (math == IVF_MATH_BF16ACT ? AM_BF16 : AM_X3),
+              BM, BN, WM, WN, pw ? "true" : "false");
   const bool timed = prof_begin(s, cls);
-  if constexpr (BN > 128 || BM == 64) {
-    if (pw)
-      hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
-  } else if (math == 0)
-    hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
-  else if (pw)
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
+  if (math == IVF_MATH_FP32) {
+    if constexpr (!wide) hipLaunchKernelGGL((conv3d_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+  } else if (math == IVF_MATH_BF16X3) {
+    launch_bf16<AM_X3, BM, BN, WM, WN>(a, pw, grid, s);
+  } else if (math == IVF_MATH_BF16ACT) {
+    launch_bf16<AM_BF16, BM, BN, WM, WN>(a, pw, grid, s);
+  } else {
+    if constexpr (fits_x6) launch_bf16<AM_X6, BM, BN, WM, WN>(a, pw, grid, s);
+  }
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
@@ -537,6 +548,10 @@ int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s) {
 }
 
 static inline int pack_ldw(int K, int math) { return math ? (K + 7) / 8 * 8 : K; }
+// floats a packed [rows][ldw] matrix occupies: fp32, or 2 / 3 bf16 planes
+static inline size_t pack_floats(size_t rows, int ldw, int math) {
+  return math ? (rows * ldw * math_planes(math) + 1) / 2 : rows * ldw;
+}
 
 // Extent / front offset of the backward conv along one dim.  Input x = s*blk + par
 // receives from outputs o with forward tap k = x + pad - s*o in [0,k): o = blk + d,
@@ -625,7 +640,12 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   if (d->gate_in)
     IVF_CHECK_ARG(relu_mask == nullptr && (d->gate_in_coff & 3) == 0 && d->gate_in_ld > 0,
                   "conv3d: gate_in replaces relu_mask (give one of them) and needs a 4-aligned channel offset");
-  IVF_CHECK_ARG(d->math == 0 || d->math == 1, "conv3d: math must be 0 (fp32 MFMA) or 1 (split-bf16 x3)");
+  IVF_CHECK_ARG(d->math >= IVF_MATH_FP32 && d->math <= IVF_MATH_BF16ACT, "conv3d: math must be one of IVF_MATH_* (0..3)");
+  if (d->math == IVF_MATH_BF16ACT) {
+    // bf16 storage on both sides, except: the 4-channel-pixel strided conv reads fp32 pixels (pix4 kernel only), a
+    // depth-to-space backward writes fp32 (LDS-halo kernel only)
+    IVF_CHECK_ARG(!(d->d2s && (d->accumulate || d->relu)), "conv3d: bf16act depth-to-space output is a plain fp32 store");
+  }
   a.ldw = pack_ldw(a.K, d->math);
   a.wbf = reinterpret_cast<const unsigned short*>(w_packed);
   a.w_lo_off = (long)d->Cout * a.ldw;
@@ -645,20 +665,31 @@ extern "C" int ivf_conv3d(const ivf_conv3d_desc* d, const float* in, const float
   }
   if (d->math == 0) IVF_CHECK_ARG(a.ldw == a.K, "conv3d: internal ldw");
   static const bool no_halo = getenv("IVF_NO_HALO") != nullptr;   // A/B switch for measurements
+  const bool bf = d->math != IVF_MATH_FP32;
+  // bf16act: which kernels can serve the two mixed-storage ends of the network
+  const bool act_stem = d->math == IVF_MATH_BF16ACT && conv_pix4_supported(a);   // fp32 pixels in: pix4 only
+  const bool act_d2s = d->math == IVF_MATH_BF16ACT && d->d2s;                     // fp32 out: LDS-halo only
   if (d->variant != IVF_CONV_AUTO) {
     // explicit kernel variant (set by the plan's tuner)
     if (d->variant == IVF_CONV_PIX4) {
-      IVF_CHECK_ARG(d->math == 1 && conv_pix4_supported(a), "conv3d: pix4 variant needs split-bf16, 4-channel pixels, stride (1|2,2,2), k <= 7");
-      return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
+      IVF_CHECK_ARG(bf && conv_pix4_supported(a), "conv3d: pix4 variant needs a split-bf16 mode, 4-channel pixels, stride (1|2,2,2), k <= 7");
+      return conv_pix4_launch(a, d->math, IVF_CONV_PIX4, (hipStream_t)stream);
     }
+    IVF_CHECK_ARG(!act_stem, "conv3d: bf16act reads fp32 pixels through the pix4 kernel only");
     if (d->variant >= IVF_CONV_HALO_BASE) {
-      IVF_CHECK_ARG(d->math == 1 && conv_halo_supported(a), "conv3d: halo variant needs split-bf16, stride 1, k in 2..4");
-      return conv_halo_launch_variant(a, d->variant - IVF_CONV_HALO_BASE, (hipStream_t)stream);
+      IVF_CHECK_ARG(bf && conv_halo_supported(a), "conv3d: halo variant needs a split-bf16 mode, stride 1, k in 2..4");
+      return conv_halo_launch_variant(a, d->math, d->variant - IVF_CONV_HALO_BASE, (hipStream_t)stream);
     }
+    IVF_CHECK_ARG(!act_d2s, "conv3d: bf16act depth-to-space (fp32 output) is served by the LDS-halo kernel only");
     return conv_igemm_launch_variant(a, d->math, d->variant - IVF_CONV_IGEMM_BASE, (hipStream_t)stream);
   }
-  if (d->math == 1 && !no_halo && !d->out2 && conv_halo_supported(a)) return conv_halo_launch(a, (hipStream_t)stream);
-  if (d->math == 1 && !no_halo && !d->out2 && !a.gbo && conv_pix4_supported(a)) return conv_pix4_launch(a, IVF_CONV_PIX4, (hipStream_t)stream);
+  if (act_stem) {
+    IVF_CHECK_ARG(!d->out2 && !a.gbo, "conv3d: the pix4 kernel has no second output window / gate record");
+    return conv_pix4_launch(a, d->math, IVF_CONV_PIX4, (hipStream_t)stream);
+  }
+  if (bf && (!no_halo || act_d2s) && !d->out2 && conv_halo_supported(a)) return conv_halo_launch(a, d->math, (hipStream_t)stream);
+  IVF_CHECK_ARG(!act_d2s, "conv3d: bf16act depth-to-space needs the LDS-halo kernel (stride-1 form, k <= 4, Cin %% 8 == 0)");
+  if (bf && !no_halo && !d->out2 && !a.gbo && conv_pix4_supported(a)) return conv_pix4_launch(a, d->math, IVF_CONV_PIX4, (hipStream_t)stream);
   return conv_launch(a, d->math, (hipStream_t)stream);
 }
 
@@ -673,14 +704,14 @@ extern "C" int ivf_bn_fold(const float* gamma, const float* beta, const float* m
 }
 
 extern "C" size_t ivf_conv3d_pack_fwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int math) {
-  return (size_t)Cout * pack_ldw(kT * kH * kW * CinPad, math);
+  return pack_floats((size_t)Cout, pack_ldw(kT * kH * kW * CinPad, math), math);
 }
 
 extern "C" int ivf_conv3d_pack_fwd_rows(const float* w_ref, float* w_packed, int Cout, int Cin, int CinPad,
                                         int kT, int kH, int kW, int row0, int rows_total, int math,
                                         ivf_stream_t stream) {
   IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0 &&
-                    (math == 0 || math == 1) && row0 >= 0 && row0 + Cout <= rows_total,
+                    (math >= 0 && math <= IVF_MATH_BF16ACT) && row0 >= 0 && row0 + Cout <= rows_total,
                 "pack_fwd: bad args");
   int taps = kT * kH * kW;
   int ldw = pack_ldw(taps * CinPad, math);
@@ -701,7 +732,7 @@ extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float
                                    int sH, int sW, int pT, int pH, int pW, int math,
                                    ivf_conv3d_bwd_geom* geom, ivf_stream_t stream) {
   IVF_CHECK_ARG(w_ref && w_packed && geom && Cout > 0 && Cout % 4 == 0 && Cin > 0 && CinPad >= Cin &&
-                    (math == 0 || math == 1),
+                    (math >= 0 && math <= IVF_MATH_BF16ACT),
                 "pack_bwd: bad args (Cout must be a multiple of 4)");
   IVF_CHECK_ARG(sT >= 1 && sT <= 2 && sH >= 1 && sH <= 2 && sW >= 1 && sW <= 2,
                 "pack_bwd: strides must be 1 or 2");
@@ -738,12 +769,12 @@ extern "C" int ivf_conv3d_pack_bwd(const float* w_ref, const float* scale, float
 
 extern "C" size_t ivf_conv3d_pack_bwd_elems(int Cout, int CinPad, int kT, int kH, int kW, int sT, int sH,
                                             int sW, int pT, int pH, int pW, int math) {
-  if (sT == 1 && sH == 1 && sW == 1) return (size_t)CinPad * pack_ldw(kT * kH * kW * Cout, math);
+  if (sT == 1 && sH == 1 && sW == 1) return pack_floats((size_t)CinPad, pack_ldw(kT * kH * kW * Cout, math), math);
   int KT, KH, KW, o;
   bwd_span(kT, sT, pT, &KT, &o);
   bwd_span(kH, sH, pH, &KH, &o);
   bwd_span(kW, sW, pW, &KW, &o);
-  return (size_t)8 * CinPad * pack_ldw(KT * KH * KW * Cout, math);
+  return pack_floats((size_t)8 * CinPad, pack_ldw(KT * KH * KW * Cout, math), math);
 }
 
 // candidate kernel variants for a descriptor: fills ids[], returns the count
@@ -751,27 +782,31 @@ extern "C" int ivf_conv3d_variants(const ivf_conv3d_desc* d, int* ids, int max_i
   if (!d || !ids) return 0;
   int n = 0;
   for (int v = 0; v < 3 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
-  if (d->math == 1 && d->kT * d->kH * d->kW == 1)
-    for (int v = 3; v < 8 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
+  const bool bf = d->math != IVF_MATH_FP32;
+  if (bf && d->kT * d->kH * d->kW == 1)
+    for (int v = (d->math == IVF_MATH_BF16X6 ? 6 : 3); v < 8 && n < max_ids; ++v) ids[n++] = IVF_CONV_IGEMM_BASE + v;
   ConvKArgs a{};
   a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.Cin = d->Cin;
   a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.d2s = d->d2s; a.in2 = d->in2;
   if (d->out2) return n;   // second output window: implicit-GEMM tiles only
-  if (d->math == 1 && conv_halo_supported(a))
+  // bf16act: the two mixed-storage ends of the network have one kernel family each
+  if (d->math == IVF_MATH_BF16ACT && conv_pix4_supported(a)) { ids[0] = IVF_CONV_PIX4; return 1; }
+  if (d->math == IVF_MATH_BF16ACT && d->d2s) n = 0;
+  if (bf && conv_halo_supported(a))
     for (int v = 0; v < conv_halo_num_variants() && n < max_ids; ++v) ids[n++] = IVF_CONV_HALO_BASE + v;
-  if (d->math == 1 && conv_pix4_supported(a) && !d->gate_out && n < max_ids) ids[n++] = IVF_CONV_PIX4;
+  if (bf && conv_pix4_supported(a) && !d->gate_out && n < max_ids) ids[n++] = IVF_CONV_PIX4;
   return n;
 }
 
 extern "C" size_t ivf_conv3d_pack_bwd_fused1x1_elems(int Ktotal, int CinPad, int math) {
-  return (size_t)CinPad * pack_ldw(Ktotal, math);
+  return pack_floats((size_t)CinPad, pack_ldw(Ktotal, math), math);
 }
 
 extern "C" int ivf_conv3d_pack_bwd_fused1x1(const float* w_ref, const float* scale, float* w_packed, int Cout,
                                             int Cin, int CinPad, int koff, int Ktotal, int math,
                                             ivf_stream_t stream) {
   IVF_CHECK_ARG(w_ref && w_packed && Cout > 0 && Cin > 0 && CinPad >= Cin && koff >= 0 && koff % 4 == 0 &&
-                    koff + Cout <= Ktotal && (math == 0 || math == 1),
+                    koff + Cout <= Ktotal && (math >= 0 && math <= IVF_MATH_BF16ACT),
                 "pack_bwd_fused1x1: bad args");
   int ldw = pack_ldw(Ktotal, math);
   size_t total = (size_t)CinPad * (Cout + ldw - Ktotal);

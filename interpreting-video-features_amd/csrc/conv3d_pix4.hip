@@ -30,22 +30,31 @@
 namespace ivf {
 
 namespace {
-constexpr int P4_TT = 4, P4_TH = 8, P4_TW = 8;
+constexpr int P4_TH = 8, P4_TW = 8;
 constexpr int P4_BN = 64;
 constexpr int P4_PW = 24;                  // LDS pixels per halo row
 constexpr int P4_COLS = 2 * (P4_TW - 1) + 8;   // staged pixels per halo row (22)
-constexpr int P4_NT = P4_TT * 2 * 64;      // one wave per 32 output rows
 constexpr int P4_ROWB = (32 + 8) * 2;      // weight tile row bytes (80: conflict-free 16-byte reads)
-constexpr int P4_NSTG = 12;               // pixels per thread of the largest box image (13 x 21 x 22)
+// MFMA passes of an operand mode as (activation plane, weight plane) pairs, smallest terms first; the kernel runs a
+// pass over both column tiles before the next one (no two consecutive MFMAs on one accumulator)
+template <int AM> struct P4Passes;
+template <> struct P4Passes<AM_X3> { static constexpr int N = 3; static constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0}; };
+template <> struct P4Passes<AM_X6> { static constexpr int N = 6; static constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0}; };
 }  // namespace
 
-__global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int tilesT, int tilesH, int tilesW) {
+// AM = operand mode (AM_X3: pixels and weights split hi/lo, AM_X6: three ways, six passes); P4_TT = frames of outputs per
+// box (4; 2 where the third pixel image has to fit the LDS); OB = the epilogue stores bf16 (the bf16-activation mode,
+// whose stem still reads fp32 pixels: its operands are AM_X3).
+template <int AM, int P4_TT, bool OB>
+__global__ __launch_bounds__(P4_TT * 2 * 64) void conv3d_pix4_kernel(ConvKArgs a, int tilesT, int tilesH, int tilesW) {
+  constexpr int NPA = OpPlanes<AM>::A, NPB = OpPlanes<AM>::B;
+  constexpr int P4_NT = P4_TT * 2 * 64;      // one wave per 32 output rows
+  constexpr int P4_NSTG = (((P4_TT - 1) * 2 + 7) * (2 * (P4_TH - 1) + 7) * P4_COLS + P4_NT - 1) / P4_NT;   // pixels per thread of the largest box image
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HT = (P4_TT - 1) * a.sT + a.kT, HH = 2 * (P4_TH - 1) + a.kH;
-  const int plane = HT * HH * P4_PW * 8;   // bytes of one (hi or lo) image
-  unsigned char* a_hi = smem;
-  unsigned char* a_lo = smem + plane;
-  unsigned char* b_base = smem + 2 * (size_t)plane;   // [3 buffers][hi, lo][64 rows][P4_ROWB]
+  const int plane = HT * HH * P4_PW * 8;   // bytes of one image plane
+  unsigned char* a_hi = smem;              // NPA planes, `plane` bytes apart
+  unsigned char* b_base = smem + NPA * (size_t)plane;   // [3 buffers][NPB planes][64 rows][P4_ROWB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wm = tid >> 6;
@@ -82,45 +91,57 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
 
   // weight ring: thread -> (plane, row, 8-value piece) of the 64 x 32 step tile
   constexpr int PF = 3;
-  uint2 rb[PF][2];
-  const int bpl = tid >> 8, brow = perm8((tid & 255) >> 2), bg = tid & 3;   // perm8: conflict-free 16-byte LDS writes
+  constexpr int NSL = NPB * 256 / P4_NT;   // (plane, row, piece) slots of the step tile per thread
+  static_assert(NSL * P4_NT == NPB * 256, "weight-stream slots must divide over the threads");
+  uint2 rb[PF][NSL][2];
   auto load_b = [&](int slot, int step) {
-    const int n = ld_n0 + brow, k0 = 8 * bg;
-    uint2 v0 = make_uint2(0u, 0u), v1 = v0;
-    if (n < a.Cout) {
-      const unsigned short* p = a.wbf + (bpl ? a.w_lo_off : 0) + (size_t)n * a.ldw + (size_t)step * kw4 + k0;
-      if (k0 < kw4) v0 = *reinterpret_cast<const uint2*>(p);
-      if (k0 + 4 < kw4) v1 = *reinterpret_cast<const uint2*>(p + 4);
+#pragma unroll
+    for (int q = 0; q < NSL; ++q) {
+      const int i = tid + q * P4_NT;
+      const int bpl = i >> 8, brow = perm8((i & 255) >> 2), bg = i & 3;   // perm8: conflict-free 16-byte LDS writes
+      const int n = ld_n0 + brow, k0 = 8 * bg;
+      uint2 v0 = make_uint2(0u, 0u), v1 = v0;
+      if (n < a.Cout) {
+        const unsigned short* p = a.wbf + bpl * a.w_lo_off + (size_t)n * a.ldw + (size_t)step * kw4 + k0;
+        if (k0 < kw4) v0 = *reinterpret_cast<const uint2*>(p);
+        if (k0 + 4 < kw4) v1 = *reinterpret_cast<const uint2*>(p + 4);
+      }
+      rb[slot][q][0] = v0;
+      rb[slot][q][1] = v1;
     }
-    rb[slot][0] = v0;
-    rb[slot][1] = v1;
   };
   auto store_b = [&](int slot, int buf) {
-    unsigned char* dst = b_base + (size_t)(buf * 2 + bpl) * P4_BN * P4_ROWB + brow * P4_ROWB + 16 * bg;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(rb[slot][0].x, rb[slot][0].y, rb[slot][1].x, rb[slot][1].y);
+#pragma unroll
+    for (int q = 0; q < NSL; ++q) {
+      const int i = tid + q * P4_NT;
+      const int bpl = i >> 8, brow = perm8((i & 255) >> 2), bg = i & 3;
+      unsigned char* dst = b_base + (size_t)(buf * NPB + bpl) * P4_BN * P4_ROWB + brow * P4_ROWB + 16 * bg;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(rb[slot][q][0].x, rb[slot][q][0].y, rb[slot][q][1].x, rb[slot][q][1].y);
+    }
   };
   // Fragment sets: while the MFMAs of step s run on set s&1, the fragments of step s+1 are
   // already being read into the other set.  The weight tile of step s+1 became visible at the
   // barrier that ended step s-1 (three LDS buffers: step s reads s%3, prefetches (s+1)%3 and
   // writes (s+2)%3), so no LDS latency sits between a barrier and the first MFMA after it.
-  bf16x8 fa[2][2][2];      // [set][ks][hi, lo]
-  bf16x8 fb[2][2][2][2];   // [set][ks][j][hi, lo]
+  bf16x8 fa[2][2][NPA];      // [set][ks][plane]
+  bf16x8 fb[2][2][2][NPB];   // [set][ks][j][plane]
   auto read_frags = [&](auto SET, int step, int buf) {
     constexpr int set = decltype(SET)::value;
     const int kt = step / a.kH, kh = step - kt * a.kH;
     const int soff = (kt * HH + kh) * P4_PW * 8;
-    const unsigned char* bh = b_base + (size_t)(buf * 2) * P4_BN * P4_ROWB;
-    const unsigned char* bl = bh + (size_t)P4_BN * P4_ROWB;
+    const unsigned char* bh = b_base + (size_t)(buf * NPB) * P4_BN * P4_ROWB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks < nks) {
-        fa[set][ks][0] = *reinterpret_cast<const bf16x8*>(a_hi + abase + soff + 32 * ks);
-        fa[set][ks][1] = *reinterpret_cast<const bf16x8*>(a_lo + abase + soff + 32 * ks);
+#pragma unroll
+        for (int pl = 0; pl < NPA; ++pl)
+          fa[set][ks][pl] = *reinterpret_cast<const bf16x8*>(a_hi + (size_t)pl * plane + abase + soff + 32 * ks);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int off = (j * 32 + li) * P4_ROWB + 32 * ks + 16 * lh;
-          fb[set][ks][j][0] = *reinterpret_cast<const bf16x8*>(bh + off);
-          fb[set][ks][j][1] = *reinterpret_cast<const bf16x8*>(bl + off);
+#pragma unroll
+          for (int pl = 0; pl < NPB; ++pl)
+            fb[set][ks][j][pl] = *reinterpret_cast<const bf16x8*>(bh + (size_t)pl * P4_BN * P4_ROWB + off);
         }
       }
     }
@@ -131,14 +152,11 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
     for (int ks = 0; ks < 2; ++ks) {
       if (ks < nks) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][ks][1], fb[set][ks][j][0], acc[j], 0, 0, 0);
+        for (int ps = 0; ps < P4Passes<AM>::N; ++ps)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][ks][0], fb[set][ks][j][1], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][ks][0], fb[set][ks][j][0], acc[j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][ks][P4Passes<AM>::pa[ps]], fb[set][ks][j][P4Passes<AM>::pb[ps]],
+                                                             acc[j], 0, 0, 0);
       }
     }
   };
@@ -174,10 +192,7 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
       const int idx = u * P4_NT + tv;
       if (idx < npx) {
         const int col = idx % P4_COLS, row = idx / P4_COLS;
-        uint2 h, l;
-        split4(stg[u], &h, &l);
-        *reinterpret_cast<uint2*>(a_hi + (row * P4_PW + col) * 8) = h;
-        *reinterpret_cast<uint2*>(a_lo + (row * P4_PW + col) * 8) = l;
+        stage_planes<AM>(a_hi + (row * P4_PW + col) * 8, (size_t)plane, stg[u]);
       }
     }
   };
@@ -242,13 +257,13 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
       const int t = ct0 + (wm >> 1), hb = ch0 + (wm & 1) * 4;
       const int wl = cw0 + 4 * lh;
       const size_t rowstride = (size_t)a.Wo * a.out_ld;
-      float* obase = a.out + ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl) * a.out_ld + a.out_coff + cn0 + li;
+      const size_t obase = ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl) * a.out_ld + a.out_coff + cn0 + li;   // (elements)
       const bool vec_ok = ((a.Cout | a.out_ld | a.out_coff) & 3) == 0;
       if (t < a.To && vec_ok) {
         // 16-byte stores: after a 4x4 transpose inside the lane quad (conv_common.h) lane q holds pixel
         // w = wl + q of each of the 4 h rows and the quad's 4 adjacent channels
         const int q = li & 3;
-        float* const qbase = a.out + ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl + q) * a.out_ld + a.out_coff;
+        const size_t qbase = ((size_t)((cb * a.To + t) * a.Ho + hb) * a.Wo + wl + q) * a.out_ld + a.out_coff;   // (elements)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = cn0 + j * 32 + li;
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
             }
             quad_transpose4(v, q);
             if (!nvalid || hb + g >= a.Ho || wl + q >= a.Wo) continue;
-            *reinterpret_cast<float4*>(qbase + (size_t)g * rowstride + nq) = make_float4(v[0], v[1], v[2], v[3]);
+            ep_st4<OB>(a.out, qbase + (size_t)g * rowstride + nq, v[0], v[1], v[2], v[3]);
           }
         }
       } else if (t < a.To) {
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(P4_NT) void conv3d_pix4_kernel(ConvKArgs a, int til
             if (!nvalid || hb + (r >> 2) >= a.Ho || wl + (r & 3) >= a.Wo) continue;
             float v = acc[j][r] * sc + sh;
             if (a.relu) v = v > 0.f ? v : 0.f;
-            obase[(r >> 2) * rowstride + (size_t)(r & 3) * a.out_ld + j * 32] = v;
+            ep_st1<OB>(a.out, obase + (r >> 2) * rowstride + (size_t)(r & 3) * a.out_ld + j * 32, v);
           }
         }
       }
@@ -297,19 +312,21 @@ int conv_pix4_supported(const ConvKArgs& a) {
   return 1;
 }
 
-int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s) {
+template <int AM, int P4_TT, bool OB>
+static int launch_pix4(ConvKArgs& a, int variant_id, hipStream_t s) {
+  constexpr int NPA = OpPlanes<AM>::A, NPB = OpPlanes<AM>::B;
   const int HT = (P4_TT - 1) * a.sT + a.kT, HH = 2 * (P4_TH - 1) + a.kH;
-  const size_t shm = (size_t)2 * HT * HH * P4_PW * 8 + (size_t)6 * P4_BN * P4_ROWB;
+  const size_t shm = (size_t)NPA * HT * HH * P4_PW * 8 + (size_t)3 * NPB * P4_BN * P4_ROWB;
   if (shm > 160 * 1024) {
     set_error("conv3d_pix4: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;
   }
   static LdsAttrOnce once;
-  IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&conv3d_pix4_kernel), 160 * 1024, once));
+  IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&conv3d_pix4_kernel<AM, P4_TT, OB>), 160 * 1024, once));
   const int tilesT = cdiv(a.To, P4_TT), tilesH = cdiv(a.Ho, P4_TH), tilesW = cdiv(a.Wo, P4_TW);
   a.ntiles = cdiv(a.Cout, P4_BN);
   a.mtiles = a.B * tilesT * tilesH * tilesW;
-  prof_name(variant_id, "conv3d_pix4_kernel");
+  prof_name(variant_id, "conv3d_pix4_kernel<%d,%d,%s>", AM, P4_TT, OB ? "true" : "false");
   const bool timed = prof_begin(s, variant_id);
   static int cus = 0;
   if (!cus) {
@@ -318,11 +335,21 @@ int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s) {
     IVF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
   const int total = a.mtiles * a.ntiles;
-  hipLaunchKernelGGL(conv3d_pix4_kernel, dim3(total < cus ? total : cus), dim3(P4_NT), shm, s, a, tilesT, tilesH,
-                     tilesW);
+  hipLaunchKernelGGL((conv3d_pix4_kernel<AM, P4_TT, OB>), dim3(total < cus ? total : cus), dim3(P4_TT * 2 * 64), shm, s, a, tilesT,
+                     tilesH, tilesW);
   if (timed) prof_end(s);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
+}
+
+int conv_pix4_launch(ConvKArgs& a, int math, int variant_id, hipStream_t s) {
+  switch (math) {
+    case IVF_MATH_BF16X3: return launch_pix4<AM_X3, 4, false>(a, variant_id, s);
+    case IVF_MATH_BF16ACT: return launch_pix4<AM_X3, 4, true>(a, variant_id, s);    // fp32 pixels in, bf16 out
+    case IVF_MATH_BF16X6: return launch_pix4<AM_X6, 2, false>(a, variant_id, s);   // 2-frame boxes: three pixel images in LDS
+  }
+  set_error("conv3d_pix4: arithmetic mode %d has no pix4 kernel", math);
+  return IVF_ERR_UNSUPPORTED;
 }
 
 }  // namespace ivf

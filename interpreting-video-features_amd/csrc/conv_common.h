@@ -28,7 +28,8 @@ struct ConvKArgs {
   int dT, dH, dW, dC;
   int bsT, bsH, bsW;  // block strides (the forward conv's strides, 1 or 2)
   int mtiles, ntiles;
-  // split-bf16 (3-pass) mode: weights as two bf16 planes [rows][ldw] (hi, then lo at +w_lo_off)
+  // split-bf16 modes: weights as bf16 planes [rows][ldw] (hi, then lo at +w_lo_off, then -- 3-way split -- the
+  // last 8 bits at +2*w_lo_off)
   const unsigned short* wbf;
   int ldw;
   long w_lo_off;
@@ -65,6 +66,87 @@ __device__ __forceinline__ void split4(const float4& v, uint2* hi, uint2* lo) {
   *lo = make_uint2(pk_bf16(v.x - hx, v.y - hy), pk_bf16(v.z - hz, v.w - hw));
 }
 
+// 3-way split x = hi + mid + lo, each 8 significant bits (bf16, RNE): both residuals are exact in fp32 and the last
+// one fits a bf16, so the three planes carry all 24 bits of an fp32 operand.
+__device__ __forceinline__ void split4x3(const float4& v, uint2* hi, uint2* mid, uint2* lo) {
+  unsigned h01 = pk_bf16(v.x, v.y), h23 = pk_bf16(v.z, v.w);
+  const float rx = v.x - __uint_as_float(h01 << 16), ry = v.y - __uint_as_float(h01 & 0xffff0000u);
+  const float rz = v.z - __uint_as_float(h23 << 16), rw = v.w - __uint_as_float(h23 & 0xffff0000u);
+  unsigned m01 = pk_bf16(rx, ry), m23 = pk_bf16(rz, rw);
+  *hi = make_uint2(h01, h23);
+  *mid = make_uint2(m01, m23);
+  *lo = make_uint2(pk_bf16(rx - __uint_as_float(m01 << 16), ry - __uint_as_float(m01 & 0xffff0000u)),
+                   pk_bf16(rz - __uint_as_float(m23 << 16), rw - __uint_as_float(m23 & 0xffff0000u)));
+}
+
+// Operand modes of the bf16-MFMA kernels (template parameter AM):
+//  AM_X3   activations fp32 in HBM, split hi/lo while staged; weights hi/lo: 3 MFMAs per k-step (lo*hi + hi*lo + hi*hi)
+//  AM_BF16 activations (and what the epilogue stores) bf16 in HBM, ONE plane staged as it is; weights hi/lo:
+//          2 MFMAs per k-step (a*lo + a*hi) -- the product a*w is as exact as in AM_X3, only storage rounds
+//  AM_X6   activations fp32, split hi/mid/lo; weights hi/mid/lo: 6 MFMAs per k-step, every term down to 2^-16 of
+//          the product (lh hl mm mh hm hh): 24-bit operands, i.e. an fp32 product to ~2^-23
+enum { AM_X3 = 0, AM_BF16 = 1, AM_X6 = 2 };
+template <int AM> struct OpPlanes {
+  static constexpr int A = AM == AM_X6 ? 3 : (AM == AM_BF16 ? 1 : 2);
+  static constexpr int B = AM == AM_X6 ? 3 : 2;
+};
+// acc += A * B over the planes of one 16-deep k-step, smallest terms first
+template <int AM>
+__device__ __forceinline__ void mma_planes(const bf16x8* fa, const bf16x8* fb, f32x16& acc) {
+  if constexpr (AM == AM_X3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
+  } else if constexpr (AM == AM_BF16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
+  }
+}
+// stage 4 channels into the A planes of one LDS row piece (8 bytes per plane, planes `pstride` bytes apart)
+template <int AM>
+__device__ __forceinline__ void stage_planes(unsigned char* dst, size_t pstride, const float4& v) {
+  if constexpr (AM == AM_X6) {
+    uint2 h, m, l;
+    split4x3(v, &h, &m, &l);
+    *reinterpret_cast<uint2*>(dst) = h;
+    *reinterpret_cast<uint2*>(dst + pstride) = m;
+    *reinterpret_cast<uint2*>(dst + 2 * pstride) = l;
+  } else if constexpr (AM == AM_X3) {
+    uint2 h, l;
+    split4(v, &h, &l);
+    *reinterpret_cast<uint2*>(dst) = h;
+    *reinterpret_cast<uint2*>(dst + pstride) = l;
+  } else {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));   // (4 bf16 carried in v.x, v.y)
+  }
+}
+// 4 channels of an activation row as the kernels stage them: a float4 of fp32 values, or (AM_BF16) the 8 bytes of 4
+// bf16 values carried bit-for-bit in .x / .y
+template <int AM>
+__device__ __forceinline__ float4 load_act4(const float* base, size_t elem_off) {
+  if constexpr (AM == AM_BF16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+  } else {
+    return *reinterpret_cast<const float4*>(base + elem_off);
+  }
+}
+// bf16 storage helpers of the AM_BF16 epilogues
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f32x4_to_bf16(float a, float b, float c, float d) { return make_uint2(pk_bf16(a, b), pk_bf16(c, d)); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float v) { return (unsigned short)(pk_bf16(v, 0.f) & 0xffffu); }
+
 // Staging writes put 8 (A, 8-byte pieces) or 4 (weights, 16-byte pieces) lanes on one 80-byte LDS
 // row; with consecutive rows on consecutive lane groups the rows of one LDS write group sit
 // 80 B apart and overlap in banks (2-way: ~30 % of all LDS cycles of these kernels were
@@ -95,9 +177,28 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int q) {
 // store (the accumulate path reads and writes the same buffer, which would otherwise
 // serialise every load behind the previous store).
 // `rowmap(local_row)` returns the flattened global output position of a tile row, or -1.
-template <int TM, int TN, class RowMap>
+// element accessors of the epilogues: fp32, or bf16 storage (offsets in ELEMENTS either way)
+template <bool OB> __device__ __forceinline__ float4 ep_ld4(const float* base, size_t off) {
+  if constexpr (OB) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off));
+  else return *reinterpret_cast<const float4*>(base + off);
+}
+template <bool OB> __device__ __forceinline__ void ep_st4(float* base, size_t off, float a, float b, float c, float d) {
+  if constexpr (OB) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = f32x4_to_bf16(a, b, c, d);
+  else *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
+}
+template <bool OB> __device__ __forceinline__ float ep_ld1(const float* base, size_t off) {
+  if constexpr (OB) return bf16_to_f32(reinterpret_cast<const unsigned short*>(base)[off]);
+  else return base[off];
+}
+template <bool OB> __device__ __forceinline__ void ep_st1(float* base, size_t off, float v) {
+  if constexpr (OB) reinterpret_cast<unsigned short*>(base)[off] = f32_to_bf16(v);
+  else base[off] = v;
+}
+
+template <int AM, int TM, int TN, class RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[TM][TN], RowMap rowmap,
                                               int row_base, int col_base, int li, int lh) {
+  constexpr bool OB = AM == AM_BF16;   // bf16 storage of out / out2 / relu_mask (the depth-to-space form always writes fp32)
   if (a.d2s) {
     // depth-to-space: n = ((pt*2+ph)*2+pw)*cpad + c with cpad == 4: the 4 channels of one
     // output pixel sit on 4 consecutive lanes; gather them with quad DPP moves and let the
@@ -169,6 +270,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
   // (DPP quad permutes) gives every lane ONE row and 4 adjacent columns, so a row group is stored by one
   // global_store_dwordx4 per lane instead of four dword stores (a wave instruction still covers whole 128-byte row
   // segments); the accumulate / gate reads become 16-byte loads the same way.  Same arithmetic per element.
+  // (bf16 storage: the same with 8-byte accesses.)
   const bool vec_ok = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && (col_base & 3) == 0 &&
                       (!a.mask || (((a.mask_ld | a.mask_coff) & 3) == 0)) &&
                       (!a.out2 || (((a.N0 | a.out2_ld | a.out2_coff) & 3) == 0));
@@ -182,7 +284,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
       const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
       const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
       const bool second = a.out2 != nullptr && nq >= a.N0;
-      float* const ocol = second ? a.out2 + a.out2_coff + (nq - a.N0) : a.out + a.out_coff + nq;
+      float* const obase = second ? a.out2 : a.out;
+      const size_t ocol = second ? (size_t)(a.out2_coff + (nq - a.N0)) : (size_t)(a.out_coff + nq);
       const size_t oldim = second ? (size_t)a.out2_ld : (size_t)a.out_ld;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -194,8 +297,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
         for (int g = 0; g < 4; ++g) {
           const int m = mrow[g] = rowmap(rbase + q + 8 * g);
           const bool ok = nvalid && m >= 0;
-          old4[g] = (a.accumulate && ok) ? *reinterpret_cast<const float4*>(ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
-          gate4[g] = (a.mask && ok) ? *reinterpret_cast<const float4*>(a.mask + (size_t)m * a.mask_ld + a.mask_coff + nq)
+          old4[g] = (a.accumulate && ok) ? ep_ld4<OB>(obase, ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gate4[g] = (a.mask && ok) ? ep_ld4<OB>(a.mask, (size_t)m * a.mask_ld + a.mask_coff + nq)
                                     : make_float4(1.f, 1.f, 1.f, 1.f);
           unsigned nib = 15u;
           if (a.gbi && ok) {
@@ -214,6 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           if (a.gbo || a.gbo2) {
             // forward record of (stored value > 0): this lane's 4 columns are a nibble, the lane 4 up (same row, next
             // 4 columns) supplies the other half of the byte; even quads write.  (No accumulate / gate here.)
+            // (bf16 storage: a positive fp32 value never rounds to zero, so the record equals (stored value > 0).)
             unsigned nib = 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -240,7 +344,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             if (!(g4[k] > 0.f) || !((gnib[g] >> k) & 1u)) t = 0.f;
             v[k] = t;
           }
-          *reinterpret_cast<float4*>(ocol + (size_t)m * oldim) = make_float4(v[0], v[1], v[2], v[3]);
+          ep_st4<OB>(obase, ocol + (size_t)m * oldim, v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -254,7 +358,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     const float sh = (a.shift && nvalid) ? a.shift[n] : 0.f;
     // this column's destination: the main window, or the second one from column N0 on
     const bool second = a.out2 != nullptr && n >= a.N0;
-    float* const ocol = second ? a.out2 + a.out2_coff + (n - a.N0) : a.out + a.out_coff + n;
+    float* const obase = second ? a.out2 : a.out;
+    const size_t ocol = second ? (size_t)(a.out2_coff + (n - a.N0)) : (size_t)(a.out_coff + n);
     const size_t oldim = second ? (size_t)a.out2_ld : (size_t)a.out_ld;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -269,8 +374,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           const int r = half * 8 + q;
           const int m = mrow[q] = rowmap(rbase + (r & 3) + 8 * (r >> 2));
           const bool ok = nvalid && m >= 0;
-          old[q] = (a.accumulate && ok) ? ocol[(size_t)m * oldim] : 0.f;
-          gate[q] = (a.mask && ok) ? a.mask[(size_t)m * a.mask_ld + a.mask_coff + n] : 1.f;
+          old[q] = (a.accumulate && ok) ? ep_ld1<OB>(obase, ocol + (size_t)m * oldim) : 0.f;
+          gate[q] = (a.mask && ok) ? ep_ld1<OB>(a.mask, (size_t)m * a.mask_ld + a.mask_coff + n) : 1.f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -279,7 +384,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           float v = acc[i][j][half * 8 + q] * sc + sh + old[q];
           if (a.relu) v = v > 0.f ? v : 0.f;
           if (!(gate[q] > 0.f)) v = 0.f;
-          ocol[(size_t)m * oldim] = v;
+          ep_st1<OB>(obase, ocol + (size_t)m * oldim, v);
         }
       }
     }
@@ -289,10 +394,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
 int conv_launch(ConvKArgs& a, int math, hipStream_t s);
 int conv_igemm_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s);
 int conv_halo_supported(const ConvKArgs& a);
-int conv_halo_launch(ConvKArgs& a, hipStream_t s);
+int conv_halo_launch(ConvKArgs& a, int math, hipStream_t s);
 int conv_halo_num_variants();
-int conv_halo_launch_variant(ConvKArgs& a, int v, hipStream_t s);
+int conv_halo_launch_variant(ConvKArgs& a, int math, int v, hipStream_t s);
 int conv_pix4_supported(const ConvKArgs& a);
-int conv_pix4_launch(ConvKArgs& a, int variant_id, hipStream_t s);
+int conv_pix4_launch(ConvKArgs& a, int math, int variant_id, hipStream_t s);
+// bf16 planes of a weight pack in an arithmetic mode (0: fp32 pack)
+static inline int math_planes(int math) { return math == IVF_MATH_BF16X6 ? 3 : (math == IVF_MATH_FP32 ? 0 : 2); }
 
 }  // namespace ivf

@@ -22,7 +22,8 @@ namespace ivf {
 struct ActBuf {
   int T, H, W, C;     // channels-last [B,T,H,W,C]
   bool relu_out;      // produced by Unit3D ReLU (or a concat of such)
-  size_t act_off = 0, grad_off = 0;   // float offsets into the workspace
+  size_t act_off = 0, grad_off = 0;   // BYTE offsets into the workspace
+  int esz = 4;                        // bytes per stored element: 4, or 2 (bf16 storage, IVF_MATH_BF16ACT; never the clip)
   // 1-bit ReLU gate record (1 byte per 8 channels, written by the forward epilogues of the producers): kept for
   // buffers whose gradient a convolution gates, so the backward reads 1/32 of the bytes of the fp32 activation
   bool need_gate = false;
@@ -106,8 +107,10 @@ struct ivf_i3d {
   // 600 us of side work ran beside it).
   bool overlap = false;
 
-  float* act(int i) const { return (float*)ws + bufs[i].act_off; }
-  float* grad(int i) const { return (float*)ws + bufs[i].grad_off; }
+  // (typed float* for the C-ABI's sake: in an IVF_MATH_BF16ACT plan every buffer but the clip holds bf16 elements)
+  float* act(int i) const { return (float*)(ws + bufs[i].act_off); }
+  float* grad(int i) const { return (float*)(ws + bufs[i].grad_off); }
+  bool act16() const { return cfg.math == IVF_MATH_BF16ACT; }
   unsigned char* gatebits(int i) const { return (unsigned char*)ws + bufs[i].gate_off; }
   template <class T>
   T* at(size_t off) const { return (T*)(ws + off); }
@@ -330,14 +333,13 @@ static int build_plan(ivf_i3d* n) {
 
   // ---- workspace layout
   const size_t B = c.B;
-  size_t fl = 0;  // floats
-  auto takef = [&](size_t elems) { size_t o = fl; fl += (elems + 63) / 64 * 64; return o; };
-  for (auto& bf : n->bufs) {
-    bf.act_off = takef(B * bf.per_clip());
-    bf.grad_off = takef(B * bf.per_clip());
-  }
-  size_t bytes = fl * sizeof(float);
+  size_t bytes = 0;
   auto takeb = [&](size_t nbytes) { size_t o = bytes; bytes += align_up(nbytes, 256); return o; };
+  for (auto& bf : n->bufs) {
+    bf.esz = (n->act16() && bf.name != "input") ? 2 : 4;
+    bf.act_off = takeb(B * bf.per_clip() * bf.esz);
+    bf.grad_off = takeb(B * bf.per_clip() * bf.esz);
+  }
   for (auto& o : n->ops)
     if (o.type == Op::POOL) {
       const ActBuf& d = n->bufs[o.dst];
@@ -464,6 +466,7 @@ static void fill_pool(const ivf_i3d* n, const Op& o, int b, ivf_pool3d_desc* d) 
   // (not for the Grad-CAM target: the hook of grad-cam.py:50-51 sees the gradient w.r.t. the endpoint's
   // OUTPUT, before its own ReLU gate, so the true arg-max must be kept even in dead windows)
   d->gate_nonpos = o.bwd_mask && o.src != n->cam_buf;
+  d->act_bf16 = n->act16();
 }
 
 static int check_ready(const ivf_i3d* n, int b) {
@@ -549,9 +552,9 @@ static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream
   const ConvLayer& L = n->convs.back();
   float* lg = n->at<float>(n->off_logits);
   float* pr = n->at<float>(n->off_probs);
-  IVF_PROPAGATE(ivf_head_fwd(n->act(n->feat_buf), n->warena + L.wf_off, n->warena + L.shift_off,
-                             n->at<float>(n->off_pooled), lg, pr, b, f.T * f.H * f.W, f.C, n->cfg.num_classes,
-                             n->cfg.softmax, s));
+  IVF_PROPAGATE((n->act16() ? ivf_head_fwd_bf16 : (decltype(&ivf_head_fwd_bf16))ivf_head_fwd)(
+      n->act(n->feat_buf), n->warena + L.wf_off, n->warena + L.shift_off, n->at<float>(n->off_pooled), lg, pr, b,
+      f.T * f.H * f.W, f.C, n->cfg.num_classes, n->cfg.softmax, s));
   size_t nb = (size_t)b * n->cfg.num_classes * sizeof(float);
   if (logits) IVF_CHECK_HIP(hipMemcpyAsync(logits, lg, nb, hipMemcpyDeviceToDevice, s));
   if (probs) IVF_CHECK_HIP(hipMemcpyAsync(probs, pr, nb, hipMemcpyDeviceToDevice, s));
@@ -563,9 +566,9 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
                         hipStream_t s) {
   const ActBuf& f = n->bufs[n->feat_buf];
   const ConvLayer& Lh = n->convs.back();
-  IVF_PROPAGATE(ivf_head_bwd(n->act(n->feat_buf), n->warena + Lh.wf_off, n->at<float>(n->off_probs), target,
-                             dout, score, nullptr, n->grad(n->feat_buf), b, f.T * f.H * f.W, f.C,
-                             n->cfg.num_classes, n->cfg.softmax, 1, s));
+  IVF_PROPAGATE((n->act16() ? ivf_head_bwd_bf16 : (decltype(&ivf_head_bwd_bf16))ivf_head_bwd)(
+      n->act(n->feat_buf), n->warena + Lh.wf_off, n->at<float>(n->off_probs), target, dout, score, nullptr,
+      n->grad(n->feat_buf), b, f.T * f.H * f.W, f.C, n->cfg.num_classes, n->cfg.softmax, 1, s));
   SideLane lane(n, s);
   IVF_PROPAGATE(lane.rc);
   int module = -1;
@@ -654,7 +657,7 @@ extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
   IVF_CHECK_ARG(cfg->stem_stride_t >= 1 && cfg->stem_stride_t <= 2 && cfg->pool4a_stride_t >= 1 &&
                     cfg->pool4a_stride_t <= 2 && cfg->pool5a_stride_t >= 1 && cfg->pool5a_stride_t <= 2,
                 "i3d_create: temporal strides must be 1 or 2");
-  IVF_CHECK_ARG(cfg->math == IVF_MATH_FP32 || cfg->math == IVF_MATH_BF16X3, "i3d_create: unknown math mode");
+  IVF_CHECK_ARG(cfg->math >= IVF_MATH_FP32 && cfg->math <= IVF_MATH_BF16ACT, "i3d_create: unknown math mode");
   ivf_i3d* n = new ivf_i3d();
   n->cfg = *cfg;
   n->overlap = getenv("IVF_OVERLAP") != nullptr && getenv("IVF_OVERLAP")[0] == '1';
@@ -882,12 +885,13 @@ extern "C" int ivf_i3d_gradcam(ivf_i3d_t* net, const float* x, int b, const int*
   float* draw = net->at<float>(net->off_dfeat_raw);
   // gradient of the (post-softmax) class score w.r.t. Mixed_5c, ungated (the hook of
   // pytorch-grad-cam/grad-cam.py:50-51 sees the raw gradient)
-  IVF_PROPAGATE(ivf_head_bwd(net->act(net->feat_buf), net->warena + Lh.wf_off, net->at<float>(net->off_probs),
-                             target, nullptr, nullptr, nullptr, draw, b, npos, f.C, c.num_classes, c.softmax,
-                             0, s));
+  IVF_PROPAGATE((net->act16() ? ivf_head_bwd_bf16 : (decltype(&ivf_head_bwd_bf16))ivf_head_bwd)(
+      net->act(net->feat_buf), net->warena + Lh.wf_off, net->at<float>(net->off_probs), target, nullptr, nullptr, nullptr,
+      draw, b, npos, f.C, c.num_classes, c.softmax, 0, s));
   float* wts = net->at<float>(net->off_camw);
   float* cm = net->at<float>(net->off_cam);
-  IVF_PROPAGATE(ivf_gradcam_reduce(net->act(net->feat_buf), draw, wts, cm, b, npos, f.C, s));
+  IVF_PROPAGATE((net->act16() ? ivf_gradcam_reduce_bf16 : (decltype(&ivf_gradcam_reduce_bf16))ivf_gradcam_reduce)(
+      net->act(net->feat_buf), draw, wts, cm, b, npos, f.C, s));
   IVF_CHECK_ARG(c.T / f.T >= 1, "i3d_gradcam: clip shorter than the feature map");
   return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, f.T, f.H, f.W, out_h, out_w,
                                   c.T / f.T, per_frame, s);
@@ -918,10 +922,14 @@ extern "C" int ivf_i3d_gradcam_layer(ivf_i3d_t* net, const float* x, int b, cons
   const int npos = t.T * t.H * t.W;
   float* wts = net->at<float>(net->off_camw);
   float* cm = net->at<float>(net->off_cam);
-  IVF_PROPAGATE(ivf_gradcam_reduce(net->act(X), net->grad(X), wts, cm, b, npos, t.C, s));
+  IVF_PROPAGATE((net->act16() ? ivf_gradcam_reduce_bf16 : (decltype(&ivf_gradcam_reduce_bf16))ivf_gradcam_reduce)(
+      net->act(X), net->grad(X), wts, cm, b, npos, t.C, s));
   return ivf_cam_resize_normalise(cm, cam, net->at<float>(net->off_mm), b, t.T, t.H, t.W, out_h, out_w, c.T / t.T,
                                   per_frame, s);
 }
+
+/* bytes per stored activation / gradient element of the plan's endpoints: 4, or 2 (bf16) for IVF_MATH_BF16ACT */
+extern "C" int ivf_i3d_act_elem_bytes(const ivf_i3d_t* net) { return (net && net->act16()) ? 2 : 4; }
 
 extern "C" double ivf_i3d_conv_flops_per_clip(const ivf_i3d_t* net) {
   double f = 0.0;

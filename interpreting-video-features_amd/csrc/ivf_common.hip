@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ivf
 
 extern "C" const char* ivf_last_error(void) { return ivf::g_err; }
-extern "C" int ivf_version(void) { return 100; }
+extern "C" int ivf_version(void) { return 300; }   // (round 3: variant table of 68 LDS-halo tiles, 4 arithmetic modes)
 
 // ---------------------------------------------------------------- launch profiler
 // Optional HIP-event timing of the implicit-GEMM convolution launches, per tile
@@ -36,7 +36,7 @@ struct Prof {
 static Prof g_prof;
 static char g_prof_names[IVF_PROFILE_CLASSES][96];
 void prof_name(int variant, const char* fmt, ...) {
-  if (variant < 0 || variant >= IVF_PROFILE_CLASSES || g_prof_names[variant][0]) return;
+  if (variant < 0 || variant >= IVF_PROFILE_CLASSES) return;   // (last call wins: a class id is reused across arithmetic modes)
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_prof_names[variant], sizeof(g_prof_names[variant]), fmt, ap);

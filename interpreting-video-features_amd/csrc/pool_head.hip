@@ -11,6 +11,29 @@
 
 namespace ivf {
 
+// Activation storage element: float, or bf16 (IVF_MATH_BF16ACT plans: 2 bytes per element, round-to-nearest-even on
+// store; a max-pool only selects, so its forward is exact in either storage).  Offsets are in elements.
+struct bf16s { unsigned short v; };
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16s* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned pk2_bf16(float lo_elem, float hi_elem) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
+  return r;
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16s* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pk2_bf16(v.x, v.y), pk2_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((unsigned)p->v << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16s* p, float v) { p->v = (unsigned short)(pk2_bf16(v, 0.f) & 0xffffu); }
+
 struct PoolArgs {
   int B, Ti, Hi, Wi, C, in_ld, in_coff;
   int To, Ho, Wo, out_ld, out_coff;
@@ -21,7 +44,8 @@ struct PoolArgs {
 // forward: scan the window in (kt,kh,kw) order over the ZERO-padded input
 // (I3D_doubled.py:36-39 pads with zeros, not -inf), first strict maximum wins
 // (torch max_pool3d semantics).  idx = flat tap of the winner (may be a pad cell).
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <class T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    unsigned char* __restrict__ idx, PoolArgs a) {
   // grid (blocks of one output row's (w, 4-channel group) cells, h, clip * frame): see maxpool_bwd_fixed_kernel
   const unsigned C4 = (unsigned)a.C >> 2;
@@ -47,8 +71,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if ((unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
               (unsigned)wi < (unsigned)a.Wi) {
-            v = *reinterpret_cast<const float4*>(
-                x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + 4 * c4);
+            v = ld4(x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + 4 * c4);
           }
           float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -62,8 +85,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
         }
       }
     }
-    *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + 4 * c4) =
-        make_float4(best[0], best[1], best[2], best[3]);
+    st4(y + m * a.out_ld + a.out_coff + 4 * c4, make_float4(best[0], best[1], best[2], best[3]));
     if (idx) {
       if (a.dead)
 #pragma unroll
@@ -77,8 +99,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 
 // backward: for every input cell sum dY of the windows whose recorded winner is
 // this cell.  dy has (out_ld, out_coff) geometry, dx has (in_ld, in_coff).
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                   float* __restrict__ dx, const float* __restrict__ relu_mask,
+template <class T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   T* __restrict__ dx, const T* __restrict__ relu_mask,
                                    int accumulate, PoolArgs a) {
   const int C4 = a.C >> 2;
   size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * C4;
@@ -109,7 +132,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
           const int tap = (kt * a.kH + kh) * a.kW + kw;
           const size_t mo = rowo + wo;
           uchar4 u = *reinterpret_cast<const uchar4*>(idx + mo * a.C + 4 * c4);
-          float4 g = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + 4 * c4);
+          float4 g = ld4(dy + mo * a.out_ld + a.out_coff + 4 * c4);
           if (u.x == tap) acc[0] += g.x;
           if (u.y == tap) acc[1] += g.y;
           if (u.z == tap) acc[2] += g.z;
@@ -117,19 +140,19 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
         }
       }
     }
-    float* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
+    T* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
     if (accumulate) {
-      float4 o = *reinterpret_cast<const float4*>(dst);
+      float4 o = ld4(dst);
       acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
     }
     if (relu_mask) {
-      float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
+      float4 k = ld4(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
       if (!(k.x > 0.f)) acc[0] = 0.f;
       if (!(k.y > 0.f)) acc[1] = 0.f;
       if (!(k.z > 0.f)) acc[2] = 0.f;
       if (!(k.w > 0.f)) acc[3] = 0.f;
     }
-    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
   }
 }
 
@@ -138,11 +161,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
 // so every candidate's (dY, arg-max) load is issued up front, unconditionally predicated --
 // no dependent loops, neighbouring cells' re-reads come from L1.  One thread per input cell
 // and 4 channels; contributions are added in ascending (to, ho, wo) order like everywhere else.
-template <int KT, int KH, int KW, int ST, int SH, int SW>
-__global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const float* __restrict__ dy,
+template <class T, int KT, int KH, int KW, int ST, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const T* __restrict__ dy,
                                                                 const unsigned char* __restrict__ idx,
-                                                                float* __restrict__ dx,
-                                                                const float* __restrict__ relu_mask, int accumulate,
+                                                                T* __restrict__ dx,
+                                                                const T* __restrict__ relu_mask, int accumulate,
                                                                 PoolArgs a) {
   constexpr int NT = (KT + ST - 1) / ST, NH = (KH + SH - 1) / SH, NW = (KW + SW - 1) / SW;
   // grid (blocks of one image row's (w, 4-channel group) cells, h, clip * frame): the row coordinates come from the
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const float* __r
         u[jt][jh][jw] = 0xffffffffu;
         if (ok) {
           const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
-          g[jt][jh][jw] = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + 4 * c4);
+          g[jt][jh][jw] = ld4(dy + mo * a.out_ld + a.out_coff + 4 * c4);
           // compare against this cell's tap: store (recorded tap XOR own tap), zero byte = match
           const unsigned tap = (unsigned)((kt * KH + kh) * KW + kw);
           u[jt][jh][jw] = *reinterpret_cast<const unsigned*>(idx + mo * a.C + 4 * c4) ^ (tap * 0x01010101u);
@@ -198,27 +221,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const float* __r
         if ((x & 0x00ff0000u) == 0u) acc[2] += v.z;
         if ((x & 0xff000000u) == 0u) acc[3] += v.w;
       }
-  float* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
+  T* dst = dx + m * a.in_ld + a.in_coff + 4 * c4;
   if (accumulate) {
-    float4 o = *reinterpret_cast<const float4*>(dst);
+    float4 o = ld4(dst);
     acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
   }
   if (relu_mask) {
-    float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
+    float4 k = ld4(relu_mask + m * a.in_ld + a.in_coff + 4 * c4);
     if (!(k.x > 0.f)) acc[0] = 0.f;
     if (!(k.y > 0.f)) acc[1] = 0.f;
     if (!(k.z > 0.f)) acc[2] = 0.f;
     if (!(k.w > 0.f)) acc[3] = 0.f;
   }
-  *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
 }
 
-template <int KT, int KH, int KW, int ST, int SH, int SW>
-static bool launch_pool_bwd_fixed(const PoolArgs& a, const float* dy, const unsigned char* idx, float* dx,
-                                  const float* relu_mask, int accumulate, hipStream_t s) {
+template <class T, int KT, int KH, int KW, int ST, int SH, int SW>
+static bool launch_pool_bwd_fixed(const PoolArgs& a, const T* dy, const unsigned char* idx, T* dx,
+                                  const T* relu_mask, int accumulate, hipStream_t s) {
   if (a.kT != KT || a.kH != KH || a.kW != KW || a.sT != ST || a.sH != SH || a.sW != SW) return false;
   if (a.Hi > 65535 || (long)a.B * a.Ti > 65535) return false;
-  hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<KT, KH, KW, ST, SH, SW>),
+  hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT, KH, KW, ST, SH, SW>),
                      dim3((unsigned)cdiv((long)a.Wi * (a.C / 4), 256), (unsigned)a.Hi, (unsigned)(a.B * a.Ti)), dim3(256), 0, s,
                      dy, idx, dx, relu_mask, accumulate, a);
   return true;
@@ -239,7 +262,8 @@ struct PoolTile {
   int slabs;
 };
 
-__global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                 unsigned char* __restrict__ idx, PoolArgs a,
                                                                 PoolTile t) {
   extern __shared__ __attribute__((aligned(16))) float sx[];   // [rT*rH*rW][POOL_ROW]
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi &&
         c0 + 4 * g < a.C)
-      v = *reinterpret_cast<const float4*>(x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
+      v = ld4(x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
                                            a.in_coff + c0 + 4 * g);
     *reinterpret_cast<float4*>(&sx[r * POOL_ROW + 4 * g]) = v;
   }
@@ -292,8 +316,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
             if (tap == 0 || vv[q] > best[q] || vv[q] != vv[q]) { best[q] = vv[q]; bi[q] = tap; }
         }
     size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
-    *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + c0 + 4 * g) =
-        make_float4(best[0], best[1], best[2], best[3]);
+    st4(y + m * a.out_ld + a.out_coff + c0 + 4 * g, make_float4(best[0], best[1], best[2], best[3]));
     if (idx) {
       if (a.dead)
 #pragma unroll
@@ -304,10 +327,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tiled_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __restrict__ dy,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const T* __restrict__ dy,
                                                                 const unsigned char* __restrict__ idx,
-                                                                float* __restrict__ dx,
-                                                                const float* __restrict__ relu_mask,
+                                                                T* __restrict__ dx,
+                                                                const T* __restrict__ relu_mask,
                                                                 int accumulate, PoolArgs a, PoolTile t, int o_lo_t,
                                                                 int o_lo_h, int o_lo_w) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dY region [n][POOL_ROW] floats, then arg-max bytes
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __r
     if ((unsigned)to < (unsigned)a.To && (unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo &&
         c0 + 4 * g < a.C) {
       size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
-      v = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + c0 + 4 * g);
+      v = ld4(dy + mo * a.out_ld + a.out_coff + c0 + 4 * g);
       u = *reinterpret_cast<const uchar4*>(idx + mo * a.C + c0 + 4 * g);
     }
     *reinterpret_cast<float4*>(&sm[r * POOL_ROW + 4 * g]) = v;
@@ -377,19 +401,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __r
       }
     }
     size_t m = ((size_t)(b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi;
-    float* dst = dx + m * a.in_ld + a.in_coff + c0 + 4 * g;
+    T* dst = dx + m * a.in_ld + a.in_coff + c0 + 4 * g;
     if (accumulate) {
-      float4 o = *reinterpret_cast<const float4*>(dst);
+      float4 o = ld4(dst);
       acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
     }
     if (relu_mask) {
-      float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + c0 + 4 * g);
+      float4 k = ld4(relu_mask + m * a.in_ld + a.in_coff + c0 + 4 * g);
       if (!(k.x > 0.f)) acc[0] = 0.f;
       if (!(k.y > 0.f)) acc[1] = 0.f;
       if (!(k.z > 0.f)) acc[2] = 0.f;
       if (!(k.w > 0.f)) acc[3] = 0.f;
     }
-    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
   }
 }
 
@@ -404,7 +428,8 @@ constexpr int S1_TH = 7;
 
 __device__ __forceinline__ bool pool_takes(float v, float best) { return v > best || v != v; }
 
-__global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                              unsigned char* __restrict__ idx, PoolArgs a, int G,
                                                              int nH, int slabs) {
   int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halo rows) on one XCD, i.e. one L2
@@ -438,7 +463,7 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __rest
           const int wi = w - 1 + j;
           v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-            v[j] = *reinterpret_cast<const float4*>(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
+            v[j] = ld4(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
                                                     a.in_coff + c);
         }
         const float v0[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
@@ -496,7 +521,7 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __rest
           pk |= k << (8 * q);
         }
         const size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + w;
-        *reinterpret_cast<float4*>(y + m * a.out_ld + a.out_coff + c) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(y + m * a.out_ld + a.out_coff + c, make_float4(o[0], o[1], o[2], o[3]));
         if (idx) {
           if (a.dead)
 #pragma unroll
@@ -522,10 +547,11 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const float* __rest
 // The 27 compare-select-adds per element bound this kernel (VALU), so it is written for
 // occupancy: ~60 registers, loads of neighbouring cells served by L1.  Contributions arrive
 // in ascending (to, ho, wo) order, as in the other backward kernels.
-__global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const float* __restrict__ dy,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* __restrict__ dy,
                                                              const unsigned char* __restrict__ idx,
-                                                             float* __restrict__ dx,
-                                                             const float* __restrict__ relu_mask, int accumulate,
+                                                             T* __restrict__ dx,
+                                                             const T* __restrict__ relu_mask, int accumulate,
                                                              PoolArgs a, int G, int slabs) {
   int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halo rows) on one XCD, i.e. one L2
   const int slab = blk % slabs; blk /= slabs;
@@ -541,20 +567,20 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const float* __rest
     for (int q = 0; q < 4; ++q) acc[p][q] = 0.f;
   auto store_plane = [&](int ti) {
     const size_t m = ((size_t)(b * a.Ti + ti) * a.Hi + h) * a.Wi + w;
-    float* dst = dx + m * a.in_ld + a.in_coff + c;
+    T* dst = dx + m * a.in_ld + a.in_coff + c;
     float o[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
     if (accumulate) {
-      float4 old = *reinterpret_cast<const float4*>(dst);
+      float4 old = ld4(dst);
       o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
     }
     if (relu_mask) {
-      float4 k = *reinterpret_cast<const float4*>(relu_mask + m * a.in_ld + a.in_coff + c);
+      float4 k = ld4(relu_mask + m * a.in_ld + a.in_coff + c);
       if (!(k.x > 0.f)) o[0] = 0.f;
       if (!(k.y > 0.f)) o[1] = 0.f;
       if (!(k.z > 0.f)) o[2] = 0.f;
       if (!(k.w > 0.f)) o[3] = 0.f;
     }
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(dst, make_float4(o[0], o[1], o[2], o[3]));
   };
   for (int to = 0; to < a.To; ++to) {
 #pragma unroll
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const float* __rest
         unsigned u = 0xffffffffu;   // matches no tap
         if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
           const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
-          gq = *reinterpret_cast<const float4*>(dy + mo * a.out_ld + a.out_coff + c);
+          gq = ld4(dy + mo * a.out_ld + a.out_coff + c);
           u = *reinterpret_cast<const unsigned*>(idx + mo * a.C + c);
         }
         const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
@@ -632,8 +658,9 @@ static void pool_bwd_tile(const PoolArgs& a, PoolTile* t) {
 // ---------------------------------------------------------------- head
 // One block per clip.  pooled[c] = mean over the npos feature cells;
 // logits[k] = bias[k] + sum_c pooled[c] W[k][c]; probs = softmax(logits).
+template <class T>
 __global__ __launch_bounds__(1024) void head_fwd_kernel(
-    const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
+    const T* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ pooled_out, float* __restrict__ logits, float* __restrict__ probs, int npos,
     int C, int K, int softmax) {
   extern __shared__ float sm[];  // C pooled + K logits + 8 scratch
@@ -641,11 +668,11 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(
   float* lg = sm + C;
   float* red = lg + K;
   const int b = blockIdx.x;
-  const float* f = feat + (size_t)b * npos * C;
+  const T* f = feat + (size_t)b * npos * C;
   const float inv = 1.f / (float)npos;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
-    for (int p = 0; p < npos; ++p) s += f[(size_t)p * C + c];
+    for (int p = 0; p < npos; ++p) s += ld1(f + (size_t)p * C + c);
     pooled[c] = s * inv;
     if (pooled_out) pooled_out[(size_t)b * C + c] = s * inv;
   }
@@ -686,10 +713,11 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(
 // softmax: dlogit[k] = p_k (dout_k - sum_j p_j dout_j); else dlogit = dout.
 // dpooled[c] = sum_k dlogit[k] W[k][c]; dfeat[b,pos,c] = dpooled[c] / npos, optionally
 // gated by (feat > 0) for the ReLU below.
+template <class T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(
-    const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ probs,
+    const T* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ probs,
     const int* __restrict__ target, const float* __restrict__ dout, float* __restrict__ score,
-    float* __restrict__ dpooled_out, float* __restrict__ dfeat, int npos, int C, int K, int softmax,
+    float* __restrict__ dpooled_out, T* __restrict__ dfeat, int npos, int C, int K, int softmax,
     int gate, int cper) {
   // grid (clip, channel slice of `cper` channels): every block recomputes the K logit gradients of its clip (a few
   // hundred flops) and finishes its own channels -- one block per clip left 3/4 of the chip idle
@@ -728,15 +756,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
   }
   __syncthreads();
   if (!dfeat) return;
-  const float* f = feat + (size_t)b * npos * C;
-  float* df = dfeat + (size_t)b * npos * C;
+  const T* f = feat + (size_t)b * npos * C;
+  T* df = dfeat + (size_t)b * npos * C;
   const int cw = c_hi - c_lo;
   for (int i = threadIdx.x; i < npos * cw; i += blockDim.x) {
     const int p = i / cw, cc = i - p * cw;
     const size_t e = (size_t)p * C + c_lo + cc;
     float v = dp[cc];
-    if (gate && !(f[e] > 0.f)) v = 0.f;
-    df[e] = v;
+    if (gate && !(ld1(f + e) > 0.f)) v = 0.f;
+    st1(df + e, v);
   }
 }
 
@@ -753,19 +781,21 @@ __global__ void argmax_kernel(const float* __restrict__ probs, int b, int K, int
 
 // ---------------------------------------------------------------- Grad-CAM
 // weights[b,k] = mean over positions of grad[b,pos,k]     (grad_cam_videos.py:98)
-__global__ void gradcam_weights_kernel(const float* __restrict__ grad, float* __restrict__ wts, int npos,
+template <class T>
+__global__ void gradcam_weights_kernel(const T* __restrict__ grad, float* __restrict__ wts, int npos,
                                        int C, int B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   int b = i / C, c = i % C;
   float s = 0.f;
-  for (int p = 0; p < npos; ++p) s += grad[((size_t)b * npos + p) * C + c];
+  for (int p = 0; p < npos; ++p) s += ld1(grad + ((size_t)b * npos + p) * C + c);
   wts[i] = s / (float)npos;
 }
 
 // cam[b,pos] = max(sum_k w[b,k] feat[b,pos,k], 0)          (grad_cam_videos.py:101-110)
 // one wave per position, lanes stride over channels
-__global__ __launch_bounds__(256) void gradcam_cam_kernel(const float* __restrict__ feat,
+template <class T>
+__global__ __launch_bounds__(256) void gradcam_cam_kernel(const T* __restrict__ feat,
                                                           const float* __restrict__ wts,
                                                           float* __restrict__ cam, int npos, int C,
                                                           int B) {
@@ -773,10 +803,10 @@ __global__ __launch_bounds__(256) void gradcam_cam_kernel(const float* __restric
   int lane = threadIdx.x & 63;
   if (gw >= B * npos) return;
   int b = gw / npos;
-  const float* f = feat + (size_t)gw * C;
+  const T* f = feat + (size_t)gw * C;
   const float* w = wts + (size_t)b * C;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += w[c] * f[c];
+  for (int c = lane; c < C; c += 64) s += w[c] * ld1(f + c);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if (lane == 0) cam[gw] = fmaxf(s, 0.f);
@@ -898,11 +928,8 @@ static PoolArgs to_args(const ivf_pool3d_desc* d) {
 
 using namespace ivf;
 
-extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float* y,
-                                 unsigned char* argmax, ivf_stream_t stream) {
-  IVF_PROPAGATE(check_pool(d));
-  IVF_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
-  PoolArgs a = to_args(d);
+template <class T>
+static int pool_fwd_impl(const PoolArgs& a, const T* x, T* y, unsigned char* argmax, hipStream_t stream) {
   static const bool direct = getenv("IVF_POOL_DIRECT") != nullptr;   // A/B switch for measurements
   PoolTile t;
   pool_fwd_tile(a, &t);
@@ -914,55 +941,58 @@ extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const float* x, float
   if (!direct && !no_s1 && pool_is_3s1(a) && a.Wi <= 256) {
     const int G = pool_3s1_groups(a), nH = cdiv(a.Hi, S1_TH), slabs = cdiv(a.C, 4 * G);
     const int threads = ((a.Wi * G + 63) / 64) * 64;
-    hipLaunchKernelGGL(maxpool3s1_fwd_kernel, dim3((unsigned)(a.B * nH * slabs)), dim3(threads), 0,
-                       (hipStream_t)stream, x, y, argmax, a, G, nH, slabs);
+    hipLaunchKernelGGL((maxpool3s1_fwd_kernel<T>), dim3((unsigned)(a.B * nH * slabs)), dim3(threads), 0, stream, x, y,
+                       argmax, a, G, nH, slabs);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
   const bool tiled_fwd = a.sT == 1 && a.sH == 1 && a.sW == 1;
   if (!direct && tiled_fwd && shm <= 64 * 1024) {
     long blocks = (long)a.B * t.nT * t.nH * t.nW * t.slabs;
-    hipLaunchKernelGGL(maxpool_fwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), shm, (hipStream_t)stream, x, y,
-                       argmax, a, t);
+    hipLaunchKernelGGL((maxpool_fwd_tiled_kernel<T>), dim3((unsigned)blocks), dim3(256), shm, stream, x, y, argmax, a, t);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
   IVF_CHECK_ARG(a.Ho <= 65535 && (long)a.B * a.To <= 65535, "maxpool_fwd: more than 65535 rows / clip-frames");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv((long)a.Wo * (a.C / 4), 256), (unsigned)a.Ho, (unsigned)(a.B * a.To)),
-                     dim3(256), 0, (hipStream_t)stream, x, y, argmax, a);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3((unsigned)cdiv((long)a.Wo * (a.C / 4), 256), (unsigned)a.Ho, (unsigned)(a.B * a.To)),
+                     dim3(256), 0, stream, x, y, argmax, a);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
 
-extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, const unsigned char* argmax,
-                                 float* dx, const float* relu_mask, int accumulate,
+extern "C" int ivf_maxpool3d_fwd(const ivf_pool3d_desc* d, const void* x, void* y, unsigned char* argmax,
                                  ivf_stream_t stream) {
   IVF_PROPAGATE(check_pool(d));
-  IVF_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null pointer");
+  IVF_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
   PoolArgs a = to_args(d);
+  if (d->act_bf16) return pool_fwd_impl<bf16s>(a, (const bf16s*)x, (bf16s*)y, argmax, (hipStream_t)stream);
+  return pool_fwd_impl<float>(a, (const float*)x, (float*)y, argmax, (hipStream_t)stream);
+}
+
+template <class T>
+static int pool_bwd_impl(const PoolArgs& a, const T* dy, const unsigned char* argmax, T* dx, const T* relu_mask,
+                         int accumulate, hipStream_t hs) {
   static const bool direct = getenv("IVF_POOL_DIRECT") != nullptr;
   PoolTile t;
   pool_bwd_tile(a, &t);
   size_t shm = (size_t)t.rT * t.rH * t.rW * (POOL_ROW * sizeof(float) + POOL_SLAB);
   static const bool no_s1 = getenv("IVF_POOL_NO_S1") != nullptr;
   if (!direct && !no_s1 && pool_is_3s1(a) && a.Wi <= 256) {
-    const int G = pool_3s1_groups(a), nH = cdiv(a.Hi, S1_TH), slabs = cdiv(a.C, 4 * G);
+    const int G = pool_3s1_groups(a), slabs = cdiv(a.C, 4 * G);
     const int threads = ((a.Wi * G + 63) / 64) * 64;
-    (void)nH;
-    hipLaunchKernelGGL(maxpool3s1_bwd_kernel, dim3((unsigned)(a.B * a.Hi * slabs)), dim3(threads), 0,
-                       (hipStream_t)stream, dy, argmax, dx, relu_mask, accumulate, a, G, slabs);
+    hipLaunchKernelGGL((maxpool3s1_bwd_kernel<T>), dim3((unsigned)(a.B * a.Hi * slabs)), dim3(threads), 0, hs, dy, argmax, dx,
+                       relu_mask, accumulate, a, G, slabs);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
   // the strided pools of the I3D variants (I3D_doubled.py:272-300; temporal strides 1 or 2)
   static const bool no_fixed = getenv("IVF_POOL_NO_FIXED") != nullptr;
   if (!direct && !no_fixed && (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4) / 256 < 0x7fffffffu) {
-    hipStream_t hs = (hipStream_t)stream;
-    if (launch_pool_bwd_fixed<1, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
-        launch_pool_bwd_fixed<3, 3, 3, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
-        launch_pool_bwd_fixed<3, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
-        launch_pool_bwd_fixed<2, 2, 2, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
-        launch_pool_bwd_fixed<2, 2, 2, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs)) {
+    if (launch_pool_bwd_fixed<T, 1, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<T, 3, 3, 3, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<T, 3, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<T, 2, 2, 2, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+        launch_pool_bwd_fixed<T, 2, 2, 2, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs)) {
       IVF_CHECK_LAUNCH();
       return IVF_OK;
     }
@@ -970,16 +1000,38 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
   // measured (16-channel slabs): the tiled gather wins 1.3-1.6x for every pool of the net
   if (!direct && shm <= 80 * 1024) {
     static LdsAttrOnce once;
-    IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&maxpool_bwd_tiled_kernel), 80 * 1024, once));
+    IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&maxpool_bwd_tiled_kernel<T>), 80 * 1024, once));
     long blocks = (long)a.B * t.nT * t.nH * t.nW * t.slabs;
-    hipLaunchKernelGGL(maxpool_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), shm, (hipStream_t)stream, dy,
-                       argmax, dx, relu_mask, accumulate, a, t, 0, 0, 0);
+    hipLaunchKernelGGL((maxpool_bwd_tiled_kernel<T>), dim3((unsigned)blocks), dim3(256), shm, hs, dy, argmax, dx, relu_mask,
+                       accumulate, a, t, 0, 0, 0);
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
   size_t total = (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy,
-                     argmax, dx, relu_mask, accumulate, a);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, hs, dy, argmax, dx, relu_mask, accumulate, a);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const void* dy, const unsigned char* argmax, void* dx,
+                                 const void* relu_mask, int accumulate, ivf_stream_t stream) {
+  IVF_PROPAGATE(check_pool(d));
+  IVF_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null pointer");
+  PoolArgs a = to_args(d);
+  if (d->act_bf16)
+    return pool_bwd_impl<bf16s>(a, (const bf16s*)dy, argmax, (bf16s*)dx, (const bf16s*)relu_mask, accumulate, (hipStream_t)stream);
+  return pool_bwd_impl<float>(a, (const float*)dy, argmax, (float*)dx, (const float*)relu_mask, accumulate, (hipStream_t)stream);
+}
+
+template <class T>
+static int head_fwd_impl(const T* feat, const float* w, const float* bias, float* pooled, float* logits, float* probs, int B,
+                         int npos, int C, int K, int softmax, ivf_stream_t stream) {
+  IVF_CHECK_ARG(feat && w && logits, "head_fwd: null pointer");
+  IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K + 8) * 4 <= 64 * 1024,
+                "head_fwd: bad dims");
+  size_t shm = (size_t)(C + K + 8) * sizeof(float);
+  hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(B), dim3(1024), shm, (hipStream_t)stream, feat, w, bias, pooled,
+                     logits, probs, npos, C, K, softmax);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
@@ -987,14 +1039,12 @@ extern "C" int ivf_maxpool3d_bwd(const ivf_pool3d_desc* d, const float* dy, cons
 extern "C" int ivf_head_fwd(const float* feat, const float* w, const float* bias, float* pooled,
                             float* logits, float* probs, int B, int npos, int C, int K, int softmax,
                             ivf_stream_t stream) {
-  IVF_CHECK_ARG(feat && w && logits, "head_fwd: null pointer");
-  IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K + 8) * 4 <= 64 * 1024,
-                "head_fwd: bad dims");
-  size_t shm = (size_t)(C + K + 8) * sizeof(float);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(1024), shm, (hipStream_t)stream, feat, w, bias, pooled,
-                     logits, probs, npos, C, K, softmax);
-  IVF_CHECK_LAUNCH();
-  return IVF_OK;
+  return head_fwd_impl<float>(feat, w, bias, pooled, logits, probs, B, npos, C, K, softmax, stream);
+}
+extern "C" int ivf_head_fwd_bf16(const void* feat, const float* w, const float* bias, float* pooled,
+                                 float* logits, float* probs, int B, int npos, int C, int K, int softmax,
+                                 ivf_stream_t stream) {
+  return head_fwd_impl<bf16s>((const bf16s*)feat, w, bias, pooled, logits, probs, B, npos, C, K, softmax, stream);
 }
 
 extern "C" int ivf_argmax(const float* probs, int b, int K, int* target, ivf_stream_t stream) {
@@ -1004,9 +1054,10 @@ extern "C" int ivf_argmax(const float* probs, int b, int K, int* target, ivf_str
   return IVF_OK;
 }
 
-extern "C" int ivf_head_bwd(const float* feat, const float* w, const float* probs, const int* target,
-                            const float* dout, float* score, float* dpooled, float* dfeat, int B,
-                            int npos, int C, int K, int softmax, int gate_relu, ivf_stream_t stream) {
+template <class T>
+static int head_bwd_impl(const T* feat, const float* w, const float* probs, const int* target, const float* dout,
+                         float* score, float* dpooled, T* dfeat, int B, int npos, int C, int K, int softmax, int gate_relu,
+                         ivf_stream_t stream) {
   IVF_CHECK_ARG(w && probs && (target || dout), "head_bwd: need probs, w and target or dout");
   IVF_CHECK_ARG(!dfeat || feat, "head_bwd: feat required with dfeat");
   IVF_CHECK_ARG(B > 0 && npos > 0 && C > 0 && K > 0 && (size_t)(C + K) * 4 <= 64 * 1024,
@@ -1014,23 +1065,45 @@ extern "C" int ivf_head_bwd(const float* feat, const float* w, const float* prob
   // channel slices of 128 (at least 4 blocks per CU's worth of clips at small batch)
   const int cper = C >= 256 ? 128 : C;
   size_t shm = (size_t)(cper + K) * sizeof(float);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(B, cdiv(C, cper)), dim3(256), shm, (hipStream_t)stream, feat, w, probs,
+  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(B, cdiv(C, cper)), dim3(256), shm, (hipStream_t)stream, feat, w, probs,
                      target, dout, score, dpooled, dfeat, npos, C, K, softmax, gate_relu, cper);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+extern "C" int ivf_head_bwd(const float* feat, const float* w, const float* probs, const int* target,
+                            const float* dout, float* score, float* dpooled, float* dfeat, int B,
+                            int npos, int C, int K, int softmax, int gate_relu, ivf_stream_t stream) {
+  return head_bwd_impl<float>(feat, w, probs, target, dout, score, dpooled, dfeat, B, npos, C, K, softmax, gate_relu, stream);
+}
+extern "C" int ivf_head_bwd_bf16(const void* feat, const float* w, const float* probs, const int* target,
+                                 const float* dout, float* score, float* dpooled, void* dfeat, int B,
+                                 int npos, int C, int K, int softmax, int gate_relu, ivf_stream_t stream) {
+  return head_bwd_impl<bf16s>((const bf16s*)feat, w, probs, target, dout, score, dpooled, (bf16s*)dfeat, B, npos, C, K,
+                              softmax, gate_relu, stream);
+}
+
+template <class T>
+static int gradcam_reduce_impl(const T* feat, const T* grad, float* weights, float* cam, int B, int npos, int C,
+                               ivf_stream_t stream) {
+  IVF_CHECK_ARG(feat && grad && weights && cam && B > 0 && npos > 0 && C > 0, "gradcam_reduce: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((gradcam_weights_kernel<T>), dim3(cdiv(B * C, 256)), dim3(256), 0, s, grad, weights, npos,
+                     C, B);
+  IVF_CHECK_LAUNCH();
+  hipLaunchKernelGGL((gradcam_cam_kernel<T>), dim3(cdiv((size_t)B * npos * 64, 256)), dim3(256), 0, s, feat,
+                     weights, cam, npos, C, B);
   IVF_CHECK_LAUNCH();
   return IVF_OK;
 }
 
 extern "C" int ivf_gradcam_reduce(const float* feat, const float* grad, float* weights, float* cam,
                                   int B, int npos, int C, ivf_stream_t stream) {
-  IVF_CHECK_ARG(feat && grad && weights && cam && B > 0 && npos > 0 && C > 0, "gradcam_reduce: bad args");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gradcam_weights_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, grad, weights, npos,
-                     C, B);
-  IVF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gradcam_cam_kernel, dim3(cdiv((size_t)B * npos * 64, 256)), dim3(256), 0, s, feat,
-                     weights, cam, npos, C, B);
-  IVF_CHECK_LAUNCH();
-  return IVF_OK;
+  return gradcam_reduce_impl<float>(feat, grad, weights, cam, B, npos, C, stream);
+}
+extern "C" int ivf_gradcam_reduce_bf16(const void* feat, const void* grad, float* weights, float* cam,
+                                       int B, int npos, int C, ivf_stream_t stream) {
+  return gradcam_reduce_impl<bf16s>((const bf16s*)feat, (const bf16s*)grad, weights, cam, B, npos, C, stream);
 }
 
 extern "C" int ivf_cam_resize_normalise(const float* cam, float* out, float* minmax_ws, int B, int nslice,

@@ -16,7 +16,7 @@ import ivf_lib as L
 
 
 # arithmetic of the Unit3D convolutions unless a caller overrides it (see include/ivf_hip.h)
-DEFAULT_MATH = os.environ.get("IVF_MATH", "bf16x3")
+DEFAULT_MATH = os.environ.get("IVF_MATH", "bf16x6")   # fp32-class: 3-way bf16 split, 6 MFMA passes
 # per-layer kernel autotuning when weights are first loaded (IVF_AUTOTUNE=0: built-in heuristic)
 AUTOTUNE = os.environ.get("IVF_AUTOTUNE", "1") != "0"
 
@@ -190,7 +190,8 @@ class I3DEngine:
                                          byref(C), byref(ld)))
         off = p.value - self._ws.data_ptr()
         n = b * T.value * H.value * W.value * ld.value
-        flat = self._ws[off:off + 4 * n].view(torch.float32)
+        esz = L.lib().ivf_i3d_act_elem_bytes(self._h)           # 2: bf16 storage (math="bf16act")
+        flat = self._ws[off:off + esz * n].view(torch.float32 if esz == 4 else torch.bfloat16).float()
         return flat.view(b, T.value, H.value, W.value, ld.value)[..., :C.value].permute(0, 4, 1, 2, 3).contiguous()
 
     def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8,

@@ -19,8 +19,8 @@ class IvfError(RuntimeError):
     pass
 
 
-MATH_FP32, MATH_BF16X3 = 0, 1
-MATH_MODES = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3}
+MATH_FP32, MATH_BF16X3, MATH_BF16X6, MATH_BF16ACT = 0, 1, 2, 3
+MATH_MODES = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6, "bf16act": MATH_BF16ACT}
 
 
 class ConvDesc(Structure):
@@ -40,7 +40,7 @@ class BwdGeom(Structure):
 class PoolDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "Ti", "Hi", "Wi", "C", "in_ld", "in_coff", "To", "Ho", "Wo", "out_ld", "out_coff",
-        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "gate_nonpos")]
+        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "gate_nonpos", "act_bf16")]
 
 
 class I3DConfig(Structure):
@@ -88,7 +88,10 @@ _SIGS = {
     "ivf_maxpool3d_bwd": (c_int, [POINTER(PoolDesc), _P, _P, _P, _P, _I, _P]),
     "ivf_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ivf_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ivf_head_fwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ivf_head_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ivf_gradcam_reduce": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ivf_gradcam_reduce_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ivf_cam_resize_normalise": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ivf_argmax": (c_int, [_P, _I, _I, _P, _P]),
     "ivf_i3d_create": (c_int, [POINTER(I3DConfig), POINTER(c_void_p)]),
@@ -106,6 +109,7 @@ _SIGS = {
     "ivf_i3d_input_grad_buffer": (c_void_p, [_P]),
     "ivf_i3d_backward": (c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "ivf_i3d_endpoint": (c_int, [_P, c_char_p, POINTER(c_void_p)] + [POINTER(c_int)] * 5),
+    "ivf_i3d_act_elem_bytes": (c_int, [_P]),
     "ivf_i3d_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     "ivf_i3d_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
     "ivf_i3d_gradcam": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P]),

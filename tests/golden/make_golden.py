@@ -416,6 +416,44 @@ def gen_search_long():
     save('search_long', **out)
 
 
+def gen_search_spread():
+    """How far do two CPU runs of the SAME reference search drift apart?  The full-length searches of
+    gen_search_long again, (a) in fp64 (model and clip in double: the arithmetic the fp32 path approximates) and
+    (b) in fp32 with another thread count (another summation order inside torch's convolutions).  Their distance to
+    the committed fp32 / 8-thread run is the noise floor of the final mask and of the mid-run trajectory: the GPU
+    tests gate their own deviation against multiples of THESE constants (not against what the GPU happens to measure)."""
+    ref = dict(np.load(os.path.join(HERE, 'search_long.npz')))
+    out = {}
+
+    def legs(tag, make_model, x, lam1, lam2, N, T):
+        for leg, dtype, threads in (('f64', torch.float64, 8), ('f32t4', torch.float32, 4)):
+            torch.set_num_threads(threads)
+            torch.set_default_dtype(dtype)
+            try:
+                m = make_model().to(dtype)
+                for p in m.parameters():
+                    p.requires_grad_(False)
+                r = _ref_search(m, x.to(dtype), int(ref[f'{tag}_target']), lam1, lam2, N, T, every=50)
+            finally:
+                torch.set_default_dtype(torch.float32)
+                torch.set_num_threads(8)
+            traj = np.asarray(r['traj'], dtype=np.float64)
+            rt = ref[f'{tag}_traj'].astype(np.float64)
+            out[f'{tag}_{leg}_mask'] = np.asarray(r['mask'], dtype=np.float64)
+            out[f'{tag}_{leg}_traj'] = traj
+            out[f'{tag}_{leg}_dmask'] = np.max(np.abs(np.asarray(r['mask'], dtype=np.float64) - ref[f'{tag}_mask']))
+            out[f'{tag}_{leg}_dloss_rel_max'] = np.max(np.abs(traj[:, 0] - rt[:, 0]) / np.abs(rt[:, 0]))
+            out[f'{tag}_{leg}_dterms_rel_max'] = np.max(np.abs(traj - rt) / np.abs(rt[:, :1]))
+            out[f'{tag}_{leg}_ranking'] = np.asarray(r['ranking'])
+            print(tag, leg, 'dmask', out[f'{tag}_{leg}_dmask'], 'dloss', out[f'{tag}_{leg}_dloss_rel_max'], 'dterms',
+                  out[f'{tag}_{leg}_dterms_rel_max'], flush=True)
+            save('search_spread', **out)
+
+    legs('c1', lambda: _clstm(1), torch.from_numpy(R.clip(3, 1, 32, 120, 160) / 255.0)[None], 0.02, 0.04, 100, 32)
+    legs('s16', lambda: _i3d(False), torch.from_numpy(R.clip(21))[None], 0.01, 0.02, 300, 16)
+    legs('k32', lambda: _i3d(True, T=32), torch.from_numpy(R.clip(23, 3, 32, 120, 160))[None], 0.02, 0.04, 100, 32)
+
+
 def gen_search_reverse():
     """temporalMaskType='reverse' (smth:121,202): the loop perturbs with the reverse
     operator, which is differentiable in the mask entries of a run (mask.py:49-56)."""
@@ -604,6 +642,36 @@ def gen_gradcam_layers():
     save('gradcam_layers', **out)
 
 
+def gen_gradcam_spread():
+    """Noise floor of the Grad-CAM maps per target layer: the reference's GradCamVideo in fp64 (model and clip in
+    double) against the committed fp32 maps of gen_gradcam_layers, and fp32 with another thread count.  The deeper the
+    target lies below the score, the more max-pool near-ties and ReLU zeros its gradient crosses; an fp32 run that
+    resolves one of them the other way re-routes gradient, and the map inherits it.  The GPU tests gate their own
+    deviation per layer against multiples of THESE figures."""
+    ref = dict(np.load(os.path.join(HERE, 'gradcam_layers.npz')))
+    out = {}
+    x = torch.from_numpy(R.clip(11))[None]
+    layers = ('Conv3d_2c_3x3', 'MaxPool3d_3a_3x3', 'Mixed_3c', 'Mixed_4c', 'Mixed_4d', 'Mixed_4e', 'Mixed_4f', 'Mixed_5b')
+    for leg, dtype, threads in (('f64', torch.float64, 8), ('f32t3', torch.float32, 3)):
+        torch.set_num_threads(threads)
+        torch.set_default_dtype(dtype)
+        try:
+            m = _i3d(False).to(dtype)
+            for layer in layers:
+                gc = ref_gc.GradCamVideo(model=m, target_layer_names=[layer], class_dict=None, use_cuda=False,
+                                         input_spatial_size=(224, 224), normalizePerFrame=True, archType="I3D")
+                cam, _ = gc(x.to(dtype), None)
+                got, want = np.asarray(cam, dtype=np.float64)[:, ::8, ::8], ref[f'{layer}_cam_small'].astype(np.float64)
+                ok = ~np.isnan(want) & ~np.isnan(got)
+                out[f'{layer}_{leg}_dmax'] = np.max(np.abs(got[ok] - want[ok]))
+                out[f'{layer}_{leg}_dmean'] = np.mean(np.abs(got[ok] - want[ok]))
+                print(layer, leg, out[f'{layer}_{leg}_dmax'], out[f'{layer}_{leg}_dmean'], flush=True)
+        finally:
+            torch.set_default_dtype(torch.float32)
+            torch.set_num_threads(8)
+    save('gradcam_spread', **out)
+
+
 def gen_ingest():
     """Clip ingest: the reference loader classes on small synthetic JPEG
     folders.  The fixture holds the JPEG bytes themselves (a few KB) and the loader output."""
@@ -651,7 +719,8 @@ def gen_ingest():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['mask_ops', 'units', 'i3d', 'clstm', 'gradcam', 'search', 'ingest',
-                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz', 'clstm_seq', 'gradcam_layers']
+                             'gradcam_k32', 'i3d_s32', 'search_reverse', 'search_long', 'viz', 'clstm_seq', 'gradcam_layers',
+                             'search_spread', 'gradcam_spread']
     for w in which:
         print('==', w, flush=True)
         globals()['gen_' + w]()

@@ -129,14 +129,21 @@ def test_clstm_full_length_search(golden):
     dmask = float(np.max(np.abs(final - g['c1_mask'])))
     note(f"full search clstm N=100: trajectory rel err max {rel.max():.2e} last {rel[-1].max():.2e}; "
          f"final mask max|d| {dmask:.2e}")
+    # the noise floor of this search, measured CPU-vs-CPU (tests/golden/search_spread.npz: the reference search in
+    # fp64 and in fp32 with another thread count against the committed run), not taken from the GPU's own deviation
+    sp = golden('search_spread')
+    cpu_dmask = max(float(sp['c1_f64_dmask']), float(sp['c1_f32t4_dmask']))
+    note(f"full search clstm: CPU-vs-CPU floor of the final mask {cpu_dmask:.2e}")
     assert rel.max() < 1e-2 and rel[-1].max() < 1e-2
-    assert dmask < 1e-2
+    mask_tol = max(1e-5, 1.5 * cpu_dmask)
+    assert dmask < mask_tol
     assert np.array_equal(final > 0.5, g['c1_mask'] > 0.5)
     rank = np.argsort(-final, kind='stable')
-    if np.min(np.diff(np.sort(g['c1_mask']))) > 2 * dmask:
+    tie_tol = 2 * mask_tol
+    if np.min(np.diff(np.sort(g['c1_mask']))) > tie_tol:
         assert np.array_equal(rank, g['c1_ranking'])
     else:
-        assert ranking_consistent(rank, g['c1_mask'], 2 * dmask + 1e-7)
+        assert ranking_consistent(rank, g['c1_mask'], tie_tol)
     rev = eng.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
     assert abs(float(rev) - float(g['c1_reverse_score'])) < 1e-3
 

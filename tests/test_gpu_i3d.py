@@ -8,8 +8,11 @@ from conftest import note, ranking_consistent, rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 
+# arithmetic modes held to the exact-fp32 gates: the fp32 MFMA chain and the 6-pass 3-way bf16 split (24-bit operands)
+EXACT = ("fp32", "bf16x6")
 
-@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+
+@pytest.fixture(scope="module", params=["fp32", "bf16x3", "bf16x6"])
 def s16(request):
     """Both arithmetic modes of the convolutions must meet the same gates."""
     import ivf_engine
@@ -19,7 +22,7 @@ def s16(request):
     return eng
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+@pytest.fixture(scope="module", params=["fp32", "bf16x3", "bf16x6"])
 def k32(request):
     import ivf_engine
     import ivf_recipe as R
@@ -67,21 +70,59 @@ def _check_forward_backward(eng, tag, shape, g, clip_id=7):
     note(f"whole-chain dx {tag} {eng.math}: sampled L2 {l2:.2e}, max {rel_err(sample, ref):.2e}")
     # measured (profiles/r02_parity_measured.txt): CPU vs CPU 0.3 % L2 / 1.0 % max; exact-fp32 MFMA 0.6-1.1 % /
     # 1.3-1.7 %; split-bf16 2.3-3.1 % / 2.8-7.7 % (its ~1e-5 arithmetic noise flips more near-ties)
-    assert l2 < (3e-2 if eng.math == "fp32" else 5e-2)
-    assert rel_err(sample, ref) < (4e-2 if eng.math == "fp32" else 1e-1)
+    assert l2 < (3e-2 if eng.math in EXACT else 5e-2)
+    assert rel_err(sample, ref) < (4e-2 if eng.math in EXACT else 1e-1)
     assert abs(np.linalg.norm(dxn.astype(np.float64)) - float(g[f'{tag}_dx_norm'])) < 1e-2 * float(g[f'{tag}_dx_norm'])
     spf = dxn[0].astype(np.float64).sum(axis=(0, 2, 3))
     # per-frame sums cancel to ~1e-6 of the gradient's norm: the most tie-sensitive figure here
-    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < (3e-2 if eng.math == "fp32" else 6e-2)
+    assert rel_err(spf, g[f'{tag}_dx_sum_per_frame']) < (3e-2 if eng.math in EXACT else 6e-2)
 
 
-def _modulewise_backward(eng, sd_np, shape, pool_kernel):
-    # element-level threshold: fp32 MFMA is an exact fp32 FMA chain; the split-bf16 mode
-    # carries ~2^-17 per product
-    thr, med_tol, frac_tol = (1e-4, 1e-6, 2e-3) if eng.math == "fp32" else (1e-3, 5e-6, 0.02)
-    """Strict backward parity: for every endpoint, run the CPU oracle's module on the
-    GPU's own input activation with the GPU's own upstream gradient and compare the
-    downstream gradient.  Identical inputs => identical ties/gates => fp32 rounding only."""
+def _cpu_module_with_gpu_gates(eng, sd, acts, name, v, flips):
+    """Forward of one endpoint (CPU oracle arithmetic) with the ReLU gates of the GPU's activations; `flips` counts
+    where the CPU's own pre-activation sign disagrees with the GPU's gate."""
+    import ivf_arch as arch
+    from oracle import i3d_ref
+
+    def gated(pre, gate):
+        flips[0] += int(((pre > 0) != gate).sum())
+        flips[1] += gate.numel()
+        return pre * gate.to(pre.dtype)
+
+    if name in arch.INCEPTION:
+        out_gate = acts[name] > 0
+        inner_gate = eng.endpoint(name + '.b12a', 1).cpu() > 0
+        c = [sd[f'{name}.{u}.conv3d.weight'].shape[0] for u in ('b0', 'b1a', 'b1b', 'b2a', 'b2b', 'b3b')]
+        o1, o2, o3 = c[0], c[0] + c[2], c[0] + c[2] + c[4]
+        b0 = gated(i3d_ref.unit3d(v, sd, name + '.b0', relu=False), out_gate[:, :o1])
+        t1 = gated(i3d_ref.unit3d(v, sd, name + '.b1a', relu=False), inner_gate[:, :c[1]])
+        b1 = gated(i3d_ref.unit3d(t1, sd, name + '.b1b', relu=False), out_gate[:, o1:o2])
+        t2 = gated(i3d_ref.unit3d(v, sd, name + '.b2a', relu=False), inner_gate[:, c[1]:])
+        b2 = gated(i3d_ref.unit3d(t2, sd, name + '.b2b', relu=False), out_gate[:, o2:o3])
+        b3 = gated(i3d_ref.unit3d(i3d_ref.maxpool_same(v, (3, 3, 3), (1, 1, 1)), sd, name + '.b3b', relu=False),
+                   out_gate[:, o3:])
+        return torch.cat([b0, b1, b2, b3], dim=1)
+    if name in arch.POOLS:
+        k, s = arch.POOLS[name]
+        return i3d_ref.maxpool_same(v, k, s)
+    stride = (2, 2, 2) if name == 'Conv3d_1a_7x7' else (1, 1, 1)
+    return gated(i3d_ref.unit3d(v, sd, name, stride, relu=False), acts[name] > 0)
+
+
+def _modulewise_backward(eng, sd_np, shape, pool_kernel, gates=None):
+    """Strict backward parity: for every endpoint, run the CPU oracle's module on the GPU's own input activation
+    with the GPU's own upstream gradient AND the GPU's own ReLU gates, and compare the downstream gradient.
+    Identical inputs => identical max-pool ties; identical gates => what is left is the rounding of the arithmetic
+    mode, gated element by element with NO outlier allowance.  (Round 2 let the CPU recompute the gates and allowed
+    a fraction of outliers; tools/diag_modulewise.py showed those outliers to be single gate flips -- one 3x3x3
+    unit's output gate within 3e-8 of zero moves 27 x 192 gradient entries -- so the flips are now counted on their
+    own: the CPU's recomputed gates against the GPU's, a handful per half million.)"""
+    # element-level threshold (x max |reference gradient| of the tensor): the fp32 MFMA chain and the 6-pass split
+    # round like fp32; the 3-pass split carries ~2^-17 per product
+    thr, fwd_tol, l2_tol = (2e-5, 1e-5, 1e-5) if eng.math in EXACT else (1e-3, 1e-4, 1e-3)
+    flip_tol = 1e-4
+    if gates is not None:
+        thr, fwd_tol, l2_tol, flip_tol = gates
     import ivf_arch as arch
     import ivf_recipe as R
     from oracle import i3d_ref
@@ -95,29 +136,23 @@ def _modulewise_backward(eng, sd_np, shape, pool_kernel):
     acts['input'] = x
     grads = {n: eng.endpoint(n + ':grad', 1).cpu() for n in arch.ENDPOINTS}
     grads['input'] = dx.cpu()
+    flips = [0, 0]      # (disagreeing gates, gates)
 
     def module(name, v):
-        if name in arch.INCEPTION:
-            return i3d_ref.inception(v, sd, name)
-        if name in arch.POOLS:
-            k, s = arch.POOLS[name]
-            return i3d_ref.maxpool_same(v, k, s)
-        stride = (2, 2, 2) if name == 'Conv3d_1a_7x7' else (1, 1, 1)
-        return i3d_ref.unit3d(v, sd, name, stride)
+        return _cpu_module_with_gpu_gates(eng, sd, acts, name, v, flips)
 
     # head: feature gradient from the class score
     f = acts['Mixed_5c'].clone().requires_grad_()
     _, out = i3d_ref.head(f, sd, pool_kernel, True)
     out[0, target].backward()
     ref = f.grad * (f > 0).float()
-    assert rel_err(grads['Mixed_5c'].numpy(), ref.numpy()) < thr
-    worst = 0.0
+    assert rel_err(grads['Mixed_5c'].numpy(), ref.numpy()) < max(thr, 1e-4)
     stats = []
     for i in range(len(names) - 1, 0, -1):
         src, dst = names[i - 1], names[i]
         v = acts[src].clone().requires_grad_()
         y = module(dst, v)
-        assert rel_err(acts[dst].numpy(), y.detach().numpy()) < thr / 10, dst      # forward, same input
+        assert rel_err(acts[dst].numpy(), y.detach().numpy()) < fwd_tol, dst      # forward, same input, same gates
         (y * grads[dst]).sum().backward()
         ref = v.grad
         if src in arch.INCEPTION or src.startswith('Conv3d'):
@@ -125,24 +160,17 @@ def _modulewise_backward(eng, sd_np, shape, pool_kernel):
         got = grads[src].numpy()
         refn = ref.numpy()
         scale = np.abs(refn).max()
-        bad = np.abs(got - refn) > thr * scale
-        # The CPU side recomputes the module's ReLU from the same input, so a gate whose
-        # pre-activation is within rounding of 0 may flip; one flip moves up to
-        # taps x Cin downstream entries.  Allow a small fraction of outliers, never a
-        # systematic error: the median must sit at fp32 rounding and the L2 error stay small.
-        # Measured (profiles/r02_parity_measured.txt): outlier fraction <= 0.0006 fp32 / 0.0063
-        # split-bf16, L2 <= 5.8e-4 / 4.1e-3; the gates sit 3x above that.
-        assert bad.mean() < frac_tol, (src, float(bad.mean()))
-        med = np.median(np.abs(got - refn)) / scale
-        assert med < med_tol, (src, med)
-        l2 = np.linalg.norm((got - refn).astype(np.float64)) / np.linalg.norm(refn.astype(np.float64))
-        assert l2 < (2e-3 if eng.math == "fp32" else 1e-2), (src, l2)
-        worst = max(worst, float(bad.mean()))
-        stats.append((src, float(bad.mean()), float(med), float(l2)))
+        err = float(np.max(np.abs(got - refn)) / scale)
+        l2 = float(np.linalg.norm((got - refn).astype(np.float64)) / np.linalg.norm(refn.astype(np.float64)))
+        stats.append((src, err, l2))
+        assert err < thr, (src, err)                   # every element: no outlier allowance
+        assert l2 < l2_tol, (src, l2)
     w = max(stats, key=lambda t: t[1])
-    note(f"module-wise backward {shape} {eng.math}: worst outlier fraction {w[1]:.4f} at {w[0]} (thr {thr:g}*scale); "
-         f"worst median {max(t[2] for t in stats):.2e}; worst L2 {max(t[3] for t in stats):.2e}")
-    return worst
+    note(f"module-wise backward {shape} {eng.math} (GPU gates on both sides): worst element error {w[1]:.2e} x max at {w[0]} "
+         f"(gate {thr:g}); worst L2 {max(t[2] for t in stats):.2e}; CPU-recomputed ReLU gates differing from the GPU's: "
+         f"{flips[0]} of {flips[1]} ({flips[0] / flips[1]:.1e})")
+    assert flips[0] <= flip_tol * flips[1]
+    return w[1]
 
 
 def test_i3d_s16_backward_modulewise(s16):
@@ -222,7 +250,8 @@ def test_tuned_plan_matches_builtin_choice(s16):
         probs, logits = eng.forward(x, want_logits=True)
         score, dx = eng.backward(2, target=tgt)
         res.append((logits.clone(), probs.clone(), score.clone(), dx.clone()))
-    tol = 1e-6 if s16.math == "fp32" else 2e-5
+    # (fp32: the tile shape does not change the k-order of an fp32 FMA chain; the split modes re-order the sums)
+    tol = {"fp32": 1e-6, "bf16x6": 5e-6}.get(s16.math, 2e-5)
     e_logits = rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
     d0, d1 = res[0][3].double(), res[1][3].double()
     e_dx = float((d1 - d0).norm() / d0.norm())
@@ -249,7 +278,7 @@ def test_tuned_plan_matches_builtin_choice_k32(k32):
     d0, d1 = res[0][1].double(), res[1][1].double()
     e_dx = float((d1 - d0).norm() / d0.norm())
     note(f"tuned vs built-in plan (K32), {k32.math}: logits max-rel {e_logits:.2e}, dx L2 {e_dx:.2e}")
-    assert e_logits < (1e-6 if k32.math == "fp32" else 2e-5)
+    assert e_logits < {"fp32": 1e-6, "bf16x6": 5e-6}.get(k32.math, 2e-5)
     assert e_dx < 5e-2
 
 
@@ -344,7 +373,7 @@ def test_search_trajectory_vs_reference(s16, golden):
     assert abs(float(rev) - float(g['s16_reverse_score'])) < 2e-3 * float(g['s16_reverse_score'])
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+@pytest.fixture(scope="module", params=["fp32", "bf16x3", "bf16x6"])
 def s32(request):
     """BASELINE configs[4] geometry: 32-frame 224x224 clips, stride_mod_layers="none" (no endpoint
     matches, head window [4,7,7])."""
@@ -391,7 +420,97 @@ def test_i3d_s32_gradcam_and_search(s32, golden):
     assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-2
 
 
-def _full_search(eng, g, tag, x, lam1, lam2, N):
+@pytest.mark.parametrize("layer", ['Conv3d_2c_3x3', 'Mixed_3c', 'Mixed_4d'])
+def test_gradcam_deep_targets_modulewise(s16, layer):
+    """Grad-CAM on a deep target WITHOUT the tie sensitivity: the CPU oracle propagates the class-score gradient from
+    the head down to the target module by module on the GPU's own activations, with the GPU's own ReLU gates (identical
+    max-pool ties, identical gates), builds the map with the oracle's reduction / resize / normalisation, and must
+    agree with the GPU's map to north_star's 1e-3 -- what separates the plain comparison above from 1e-3 is which
+    near-ties two fp32 runs break which way, not the kernels' arithmetic."""
+    import ivf_arch as arch
+    import ivf_recipe as R
+    from oracle import gradcam_ref, i3d_ref
+    sd = R.to_torch(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(11))[None]
+    cam, probs = s16.gradcam(x.cuda(), None, per_frame=True, layer=layer)
+    target = int(torch.argmax(probs[0]))
+    acts = {n: s16.endpoint(n, 1).cpu() for n in arch.ENDPOINTS}
+    f = acts['Mixed_5c'].clone().requires_grad_()
+    _, out = i3d_ref.head(f, sd, (2, 7, 7), True)
+    out[0, target].backward()
+    g = f.grad * (f > 0).float()
+    names = list(arch.ENDPOINTS)
+    flips = [0, 0]
+    for i in range(len(names) - 1, names.index(layer), -1):
+        src, dst = names[i - 1], names[i]
+        v = acts[src].clone().requires_grad_()
+        (_cpu_module_with_gpu_gates(s16, sd, acts, dst, v, flips) * g).sum().backward()
+        g = v.grad
+        if src != layer and (src in arch.INCEPTION or src.startswith('Conv3d')):
+            g = g * (v.detach() > 0).float()           # below the target the plan gates; the target's gradient stays raw
+    ref, _, _ = gradcam_ref.cam_from_activations(acts[layer].numpy()[0], g.numpy()[0], 16, 224, 224, True)
+    got = cam[0].cpu().numpy()
+    ok = ~np.isnan(ref) & ~np.isnan(got)
+    err = float(np.max(np.abs(got[ok] - ref[ok])))
+    note(f"gradcam s16 target {layer} {s16.math}, CPU chain on the GPU's activations and gates: max|d| {err:.2e} "
+         f"(CPU-recomputed gates differing: {flips[0]} of {flips[1]})")
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and err < 1e-3
+
+
+def test_bf16_activation_mode_modulewise():
+    """The bf16-activation mode module by module (S16): the CPU module on the GPU's own (bf16-valued) activations and
+    upstream gradient.  Identical inputs => identical max-pool ties and ReLU gates, so what is left is the mode's own
+    rounding: one RNE to bf16 per stored element (2^-9 relative) on top of the 2-pass products."""
+    import ivf_engine
+    import ivf_recipe as R
+    eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=1, softmax=True, math="bf16act")
+    sd = R.i3d_state_dict(num_classes=174)
+    eng.load_state_dict(sd)
+    #        element thr (x max), forward max-rel, L2, gate-flip fraction (bf16 values: a gate can sit ON zero)
+    _modulewise_backward(eng, sd, (3, 16, 224, 224), (2, 7, 7), gates=(2e-2, 4e-3, 5e-3, 1e-3))
+
+
+def test_i3d_s32_bf16_activations(golden):
+    """BASELINE configs[4] in its stated form: 32-frame 224x224 clips, bf16 ACTIVATION STORAGE (math="bf16act":
+    every activation / gradient buffer bf16 in HBM with RNE in the epilogues, weights split hi/lo = 2 MFMA passes,
+    fp32 accumulate) against the reference's fp32 outputs (i3d_s32.npz).  A storage precision of 2^-9 per layer is
+    NOT the fp32 path: the figures are recorded (profiles/rNN_parity_measured.txt) and gated at what bf16 storage
+    can hold; whether north_star's 1e-3 holds is stated in the note, not assumed."""
+    import ivf_engine
+    import ivf_recipe as R
+    g = golden('i3d_s32')
+    eng = ivf_engine.I3DEngine(174, (3, 32, 224, 224), max_batch=1, stride_mod_layers="none", last_stride=1,
+                               softmax=True, math="bf16act")
+    eng.load_state_dict(R.i3d_state_dict(num_classes=174))
+    x = torch.from_numpy(R.clip(13, 3, 32, 224, 224))[None].cuda()
+    probs, logits = eng.forward(x, want_logits=True)
+    e_l = rel_err(logits.cpu().numpy(), g['s32_logits'])
+    e_p = rel_err(probs.cpu().numpy(), g['s32_probs'])
+    assert int(torch.argmax(probs[0])) == int(g['s32_target'])              # integer output: still bit-exact
+    import ivf_arch as arch
+    worst_norm = max(abs(float(eng.endpoint(n, 1).double().norm()) / float(g[f's32_norm_{n}']) - 1.0) for n in arch.ENDPOINTS)
+    cams = {}
+    for tag, pf in (('pf', True), ('glob', False)):
+        cam, _ = eng.gradcam(x, None, per_frame=pf)
+        got, ref = cam[0].cpu().numpy()[:, ::8, ::8], g[f'gc_{tag}_cam_small']
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        cams[tag] = float(np.max(np.abs(got[ok] - ref[ok])))
+    raw = torch.from_numpy(g['srch_init'])[None].cuda().contiguous()
+    traj, _ = eng.search(x, [int(g['s32_target'])], raw, 0.01, 0.02, 3)
+    e_t = float(np.max(np.abs(traj[:, 0].cpu().numpy() - g['srch_traj']) / np.abs(g['srch_traj'])))
+    holds = max(e_l, e_p, cams['pf'], cams['glob']) < 1e-3
+    note(f"configs[4] S32 bf16 activations: logits max-rel {e_l:.2e}, probs max-rel {e_p:.2e}, endpoint norms within "
+         f"{worst_norm:.2e}, Grad-CAM max|d| per-frame {cams['pf']:.2e} / global {cams['glob']:.2e} (maps in [0,1]), "
+         f"3-iteration trajectory max-rel {e_t:.2e} -> the 1e-3 gate of the fp32 modes "
+         f"{'HOLDS' if holds else 'does NOT hold'} with bf16 storage; the 1e-2 trajectory gate "
+         f"{'holds' if e_t < 1e-2 else 'does NOT hold'}")
+    assert e_l < 2e-2 and e_p < 5e-2 and worst_norm < 1e-2          # bf16 storage: 2^-9 per layer
+    assert cams['pf'] < 1e-1 and cams['glob'] < 1e-1
+    assert e_t < 1e-2                                                 # north_star's trajectory tolerance
+
+
+def _full_search(eng, g, tag, x, lam1, lam2, N, spread):
     """The reference's FULL search length: gates of north_star at EVERY iteration including the last."""
     target = int(g[f'{tag}_target'])
     probs = eng.forward(x)
@@ -409,20 +528,30 @@ def _full_search(eng, g, tag, x, lam1, lam2, N):
          f"final mask max|d| {dmask:.2e}")
     # north_star: the mask-LOSS trajectory within 1e-2 after N iterations -- gated at every iteration and,
     # for all four terms, at the last one.  Mid-run the individual terms (l1 vs score trade along a flat
-    # direction of the loss) and the mask itself wander more than the loss: Adam(lr=0.2) amplifies
-    # last-bit gradient differences, and the EXACT-fp32 mode shows the same spread as split-bf16
-    # (profiles/r02_parity_measured.txt), so those are sanity-bounded only.
+    # direction of the loss) and the mask itself wander more than the loss: Adam(lr=0.2) amplifies last-bit
+    # gradient differences.  How much is NOT taken from what the GPU measures: tests/golden/search_spread.npz
+    # holds the same reference search run twice more on the CPU (make_golden.py gen_search_spread: fp64, and
+    # fp32 with 4 instead of 8 threads); their distance to the committed run is the noise floor of this search
+    # (S16 N=300: final mask 1.9e-2, terms 1.4e-2, loss 6.8e-3 between two fp32 CPU runs; K32: 1e-6).
+    sp = spread
+    cpu_dmask = max(float(sp[f'{tag}_f64_dmask']), float(sp[f'{tag}_f32t4_dmask']))
+    cpu_dterms = max(float(sp[f'{tag}_f64_dterms_rel_max']), float(sp[f'{tag}_f32t4_dterms_rel_max']))
+    note(f"full search {tag}: CPU-vs-CPU floor (fp64 / 4-thread fp32 vs the committed 8-thread fp32 run): final mask "
+         f"{cpu_dmask:.2e}, terms {cpu_dterms:.2e}")
     assert rel[:, 0].max() < 1e-2 and rel[-1].max() < 1e-2
-    assert rel.max() < 3e-2
-    assert dmask < 5e-2
-    # integer outputs: snapped mask and frame ranking
+    assert rel.max() < max(1e-2, 2 * cpu_dterms)              # mid-run terms: within twice what two CPU runs differ by
+    mask_tol = max(1e-5, 1.5 * cpu_dmask)                     # final mask: within 1.5x the CPU-vs-CPU distance (floor: fp32 rounding)
+    assert dmask < mask_tol
+    # integer outputs: snapped mask and frame ranking -- bit-exact wherever the reference mask separates two frames
+    # by more than the CPU-vs-CPU noise of that mask (a FIXED constant of the fixture), tie-consistent below it
     assert np.array_equal(final > 0.5, g[f'{tag}_mask'] > 0.5)
     rank = np.argsort(-final, kind='stable')
     sorted_ref = np.sort(g[f'{tag}_mask'])
-    if np.min(np.diff(sorted_ref)) > 2 * dmask:               # the reference separates all frames: bit-exact
+    tie_tol = 2 * mask_tol
+    if np.min(np.diff(sorted_ref)) > tie_tol:                 # the reference separates all frames: bit-exact
         assert np.array_equal(rank, g[f'{tag}_ranking'])
-    else:                                                     # exact ties in the reference mask itself
-        assert ranking_consistent(rank, g[f'{tag}_mask'], 2 * dmask + 1e-7)
+    else:
+        assert ranking_consistent(rank, g[f'{tag}_mask'], tie_tol)
     rev = eng.perturbed_forward(x, torch.sigmoid(raw), 'reverse')[0, target]
     assert abs(float(rev) - float(g[f'{tag}_reverse_score'])) < 1e-2 * float(g[f'{tag}_reverse_score'])
 
@@ -431,14 +560,14 @@ def test_full_length_search_s16(s16, golden):
     """N=300, lam 0.01/0.02 (smth:106-119) against the reference harness's 300-iteration run."""
     import ivf_recipe as R
     x = torch.from_numpy(R.clip(21))[None].cuda()
-    _full_search(s16, golden('search_long'), 's16', x, 0.01, 0.02, 300)
+    _full_search(s16, golden('search_long'), 's16', x, 0.01, 0.02, 300, golden('search_spread'))
 
 
 def test_full_length_search_k32(k32, golden):
     """I3D-KTH, N=100, lam 0.02/0.04 (KTH:105-118)."""
     import ivf_recipe as R
     x = torch.from_numpy(R.clip(23, 3, 32, 120, 160))[None].cuda()
-    _full_search(k32, golden('search_long'), 'k32', x, 0.02, 0.04, 100)
+    _full_search(k32, golden('search_long'), 'k32', x, 0.02, 0.04, 100, golden('search_spread'))
 
 
 def test_gradcam_k32_vs_reference(k32, golden):
@@ -503,11 +632,16 @@ def test_gradcam_other_target_layers(s16, layer, golden):
     ok = ~np.isnan(ref)
     err = float(np.max(np.abs(got[ok] - ref[ok])))
     note(f"gradcam s16 target {layer} {s16.math}: max|d| {err:.2e}, mean|d| {np.mean(np.abs(got[ok] - ref[ok])):.2e}")
-    # 1e-3 (north_star) where at most one strided max-pool lies between the target and the score; further
-    # down the map inherits the whole-chain gradient's sensitivity to max-pool near-ties (see
-    # test_whole_chain_dx_cpu_vs_cpu, which records the same figure between two CPUs)
-    deep = layer not in ('Mixed_4f', 'Mixed_5b', 'Mixed_5c')
-    assert ok.any() and err < ((1e-2 if s16.math == "fp32" else 3e-2) if deep else 1e-3)
+    # 1e-3 (north_star) wherever two CPU runs of the reference agree that well; further down, the map inherits the
+    # sensitivity of the gradient to max-pool near-ties / ReLU zeros, and the gate is 3x what the reference's own map
+    # moves between fp32 and fp64 (or another thread count) on the CPU: tests/golden/gradcam_spread.npz
+    # (make_golden.py gen_gradcam_spread; Conv3d_2c 7.5e-4, MaxPool3d_3a 1.3e-3, Mixed_3c 3.1e-4, Mixed_4e 3.8e-6).
+    # The arithmetic itself is checked without that sensitivity in test_gradcam_deep_targets_modulewise.
+    sp = golden('gradcam_spread')
+    floor = max(float(sp[f'{layer}_f64_dmax']), float(sp[f'{layer}_f32t3_dmax']))
+    gate = max(1e-3, 3 * floor) if s16.math in EXACT else max(1e-3, 3 * floor, 3e-2 if floor > 1e-4 else 1e-3)
+    note(f"gradcam s16 target {layer}: CPU-vs-CPU floor {floor:.2e}, gate {gate:.2e}")
+    assert ok.any() and err < gate
     # the ordinary passes are untouched by the ungated Grad-CAM pass before them
     p2 = s16.forward(x)
     assert torch.equal(p2, probs)

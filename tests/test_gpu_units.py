@@ -43,7 +43,7 @@ def from_cl(y, C):
     return y[..., :C].permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("name", list(UNIT_CASES))
 def test_unit3d_fwd_bwd(name, math, golden):
     import ivf_arch as arch
@@ -52,7 +52,7 @@ def test_unit3d_fwd_bwd(name, math, golden):
     lib = L.lib()
     g = golden('units')
     mm = L.MATH_MODES[math]
-    tol = 1e-5 if math == "fp32" else 1e-4      # split-bf16: ~2^-17 per product
+    tol = 1e-4 if math == "bf16x3" else 1e-5    # split-bf16 x3: ~2^-17 per product; the 6-pass split is fp32-class
     cin, cout, k, s, thw = UNIT_CASES[name]
     cinp = (cin + 3) // 4 * 4
     B = 2
@@ -239,9 +239,10 @@ def test_maxpool_gate_nonpos_equals_relu_mask(k, st, thw):
     assert bool((res[1][2] == 255).any()) and not bool((res[0][2] == 255).any())
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("k,cin,cout,thw", [(3, 32, 40, (5, 15, 30)), (3, 16, 200, (3, 9, 15)), (4, 8, 32, (4, 9, 10)),
                                             (1, 24, 72, (2, 5, 7))])
-def test_every_conv_variant_matches_torch(k, cin, cout, thw):
+def test_every_conv_variant_matches_torch(k, cin, cout, thw, math):
     """Every kernel variant the tuner may pick (ivf_conv3d_variants: implicit GEMM tiles, all
     LDS-halo boxes) computes the same convolution: compared with torch's fp64 conv3d on
     ragged sizes (partial boxes in every dimension, partial channel tiles), with the fused
@@ -258,7 +259,8 @@ def test_every_conv_variant_matches_torch(k, cin, cout, thw):
     pf, pb = (k - 1) // 2, k - 1 - (k - 1) // 2
     ref = F.conv3d(F.pad(x.double(), (pf, pb, pf, pb, pf, pb)), w.double())
     ref_relu = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1))
-    mm = L.MATH_MODES["bf16x3"]
+    mm = L.MATH_MODES[math]
+    tol = 1e-4 if math == "bf16x3" else 1e-5   # the exact-fp32 MFMA and the 6-pass split: fp32-class
     wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, k, k, k, mm), device='cuda')
     wd, scd, shd = w.cuda(), scale.cuda(), shift.cuda()   # (kept alive: L.ptr only takes the address)
     L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, cin, cin, k, k, k, mm, L.stream()))
@@ -289,11 +291,11 @@ def test_every_conv_variant_matches_torch(k, cin, cout, thw):
             continue   # variant not applicable to this shape (LDS budget)
         ran += 1
         got = from_cl(y, cout).double().cpu()
-        assert rel_err(got.numpy(), ref_relu.numpy()) < 1e-4, f"variant {v}"
+        assert rel_err(got.numpy(), ref_relu.numpy()) < tol, f"variant {v}"
         d.relu, d.accumulate = 0, 1
         acc = base.clone()
         L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), None, None, L.ptr(gate), L.ptr(acc), L.stream()))
-        assert rel_err(acc.double().cpu().numpy(), want_acc.numpy()) < 1e-4, f"variant {v} (accumulate)"
+        assert rel_err(acc.double().cpu().numpy(), want_acc.numpy()) < tol, f"variant {v} (accumulate)"
     assert ran >= 3
 
 
@@ -515,3 +517,242 @@ def test_strided_maxpool_with_ties_matches_torch(k, st, thw):
     L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gycl), L.ptr(idx), L.ptr(acc), L.ptr(xcl), 1, L.stream()))
     want = torch.where(xcl > 0, base + dxcl, torch.zeros_like(base))
     assert torch.allclose(acc, want, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ bf16 activation storage (IVF_MATH_BF16ACT)
+def _pool_desc(L, B, thw, C, k, s, bf16):
+    import ivf_arch as arch
+    pads = [arch.same_pad(n, kk, ss)[0] for n, kk, ss in zip(thw, k, s)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    d = L.PoolDesc()
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, *thw, C, C, 0
+    d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *outs, C, 0
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = s
+    d.pT, d.pH, d.pW = pads
+    d.act_bf16 = 1 if bf16 else 0
+    return d, outs
+
+
+@pytest.mark.parametrize("k,st,thw,C", [((1, 3, 3), (1, 2, 2), (3, 17, 20), 24), ((3, 3, 3), (2, 2, 2), (5, 15, 14), 40),
+                                        ((2, 2, 2), (2, 2, 2), (4, 8, 10), 16), ((3, 3, 3), (1, 1, 1), (4, 9, 8), 48)])
+def test_maxpool_bf16_storage_equals_fp32_path(k, st, thw, C):
+    """Every pool kernel family with bf16 storage (ivf_pool3d_desc.act_bf16) against the fp32 path on the same
+    bf16-representable tensors: the forward selects (identical values and arg-max, ties included), the backward sums in
+    fp32 and rounds once (= the fp32 result rounded to bf16), with and without accumulate + ReLU gate."""
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(11)
+    B = 2
+    x = (torch.randint(0, 6, (B,) + thw + (C,), generator=gen).float() / 4).bfloat16().cuda()   # many exact ties
+    res = {}
+    for bf in (False, True):
+        d, outs = _pool_desc(L, B, thw, C, k, st, bf)
+        dt = torch.bfloat16 if bf else torch.float32
+        xin = x.to(dt).contiguous()
+        y = torch.zeros((B,) + tuple(outs) + (C,), dtype=dt, device='cuda')
+        idx = torch.zeros((B,) + tuple(outs) + (C,), dtype=torch.uint8, device='cuda')
+        L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(xin), L.ptr(y), L.ptr(idx), L.stream()))
+        gy = torch.randn((B,) + tuple(outs) + (C,), generator=gen).bfloat16().to(dt).cuda() if not res else res['gy'].to(dt)
+        dx = torch.full((B,) + thw + (C,), float('nan'), dtype=dt, device='cuda')
+        L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gy), L.ptr(idx), L.ptr(dx), None, 0, L.stream()))
+        base = (torch.randn((B,) + thw + (C,), generator=torch.Generator().manual_seed(3)).bfloat16()).to(dt).cuda()
+        acc = base.clone()
+        L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(gy), L.ptr(idx), L.ptr(acc), L.ptr(xin), 1, L.stream()))
+        if not res:
+            res = dict(y=y, idx=idx, dx=dx, acc=acc, gy=gy)
+        else:
+            assert torch.equal(y.float(), res['y']) and torch.equal(idx, res['idx'])
+            assert torch.equal(dx, res['dx'].bfloat16())
+            assert torch.equal(acc, res['acc'].bfloat16())
+
+
+@pytest.mark.parametrize("k,cin,cout,thw", [(3, 32, 40, (5, 15, 30)), (3, 16, 200, (3, 9, 15)), (1, 24, 72, (2, 5, 7)),
+                                            (1, 64, 136, (4, 14, 14))])
+def test_every_conv_variant_bf16_activations(k, cin, cout, thw):
+    """IVF_MATH_BF16ACT: every kernel variant on bf16 inputs against torch fp64 on the SAME bf16 values -- the
+    products are as exact as in the split modes (weights hi/lo), so the only new error is the one RNE to bf16 of the
+    stored result (2^-9 relative): forward with BN + ReLU, and the accumulate + ReLU-gate (bf16 gate tensor) form."""
+    import torch.nn.functional as F
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn((B, cin) + thw, generator=gen).bfloat16()
+    w = torch.randn(cout, cin, k, k, k, generator=gen) * 0.1
+    scale = torch.rand(cout, generator=gen) + 0.5
+    shift = torch.randn(cout, generator=gen) * 0.1
+    pf, pb = (k - 1) // 2, k - 1 - (k - 1) // 2
+    ref = F.conv3d(F.pad(x.double(), (pf, pb, pf, pb, pf, pb)), w.double())
+    ref_relu = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1))
+    mm = L.MATH_MODES["bf16act"]
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, k, k, k, mm), device='cuda')
+    wd, scd, shd = w.cuda(), scale.cuda(), shift.cuda()
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, cin, cin, k, k, k, mm, L.stream()))
+    xcl = x.cuda().permute(0, 2, 3, 4, 1).contiguous()          # bf16 channels-last
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cin, cin, 0
+    d.To, d.Ho, d.Wo = thw
+    d.Cout, d.out_ld, d.out_coff = cout, cout, 0
+    d.kT = d.kH = d.kW = k
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = pf
+    d.math = mm
+    d.mask_ld, d.mask_coff = cout, 0
+    ids = (ctypes.c_int * 96)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96)
+    assert n >= 3
+    base = torch.randn((B,) + thw + (cout,), generator=gen).bfloat16().cuda()
+    gate = (torch.rand((B,) + thw + (cout,), generator=gen) > 0.3).to(torch.bfloat16).cuda()
+    want_acc = (base.double().cpu() + ref.permute(0, 2, 3, 4, 1)) * gate.double().cpu()
+
+    def close(got, want, what):
+        got, want = got.double().cpu(), want.double()
+        tol = 2.0 ** -8 * want.abs() + 1e-5 * want.abs().max()      # half an ulp of bf16 is 2^-9 relative
+        assert bool(((got - want).abs() <= tol).all()), what
+
+    ran = 0
+    for v in list(ids)[:n]:
+        d.variant = v
+        d.relu, d.accumulate = 1, 0
+        y = torch.full((B,) + thw + (cout,), float('nan'), dtype=torch.bfloat16, device='cuda')
+        rc = lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), L.ptr(scd), L.ptr(shd), None, L.ptr(y), L.stream())
+        if rc != 0:
+            continue
+        ran += 1
+        close(y, ref_relu.permute(0, 2, 3, 4, 1), f"variant {v}")
+        d.relu, d.accumulate = 0, 1
+        acc = base.clone()
+        L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), None, None, L.ptr(gate), L.ptr(acc), L.stream()))
+        close(acc, want_acc, f"variant {v} (accumulate)")
+    assert ran >= 3
+
+
+def test_bf16_activation_stem_ends_keep_fp32():
+    """The two mixed-storage ends of an IVF_MATH_BF16ACT network: the 4-channel-pixel strided conv reads fp32 pixels
+    and writes bf16 (pix4 only), its depth-to-space backward reads bf16 gradients and writes the fp32 input gradient
+    (LDS-halo only): against torch fp64 on the same values; every stem-backward variant the tuner may pick."""
+    import torch.nn.functional as F
+    import ivf_arch as arch
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(9)
+    B, cin, cinp, cout, k, s, thw = 2, 3, 4, 64, (7, 7, 7), (2, 2, 2), (8, 30, 36)
+    x = (torch.rand((B, cin) + thw, generator=gen) * 255).round()
+    w = torch.randn((cout, cin) + k, generator=gen) * 0.02
+    scale = torch.rand(cout, generator=gen) + 0.5
+    shift = torch.randn(cout, generator=gen) * 0.1
+    pads = [arch.same_pad(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    xp = F.pad(x.double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1])).requires_grad_()
+    y_ref = F.conv3d(xp, w.double(), stride=s) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    mm = L.MATH_MODES["bf16act"]
+    wd, scd, shd = w.cuda(), scale.cuda(), shift.cuda()
+    wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cinp, *k, mm), device='cuda')
+    L.check(lib.ivf_conv3d_pack_fwd(L.ptr(wd), L.ptr(wf), cout, cin, cinp, *k, mm, L.stream()))
+    xcl = to_cl(x.cuda(), cinp)                                   # fp32 pixels
+    d = L.ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi = B, *thw
+    d.Cin, d.in_ld, d.in_coff = cinp, cinp, 0
+    d.To, d.Ho, d.Wo = outs
+    d.Cout, d.out_ld, d.out_coff = cout, cout, 0
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = s
+    d.pT, d.pH, d.pW = [p[0] for p in pads]
+    d.relu, d.math = 1, mm
+    ids = (ctypes.c_int * 96)()
+    assert lib.ivf_conv3d_variants(ctypes.byref(d), ids, 96) == 1 and ids[0] == 15      # IVF_CONV_PIX4
+    y = torch.full((B,) + tuple(outs) + (cout,), float('nan'), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.ivf_conv3d(ctypes.byref(d), L.ptr(xcl), L.ptr(wf), L.ptr(scd), L.ptr(shd), None, L.ptr(y), L.stream()))
+    want = torch.relu(y_ref).detach().permute(0, 2, 3, 4, 1)
+    got = y.double().cpu()
+    assert bool(((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-5 * want.abs().max()).all())
+    # backward-data: bf16 upstream gradient -> fp32 input gradient, BN scale folded in the pack
+    gy = torch.randn((B,) + tuple(outs) + (cout,), generator=gen).bfloat16()
+    (y_ref * gy.double().permute(0, 4, 1, 2, 3)).sum().backward()
+    dx_ref = xp.grad[:, :, pads[0][0]:pads[0][0] + thw[0], pads[1][0]:pads[1][0] + thw[1], pads[2][0]:pads[2][0] + thw[2]]
+    wb = torch.empty(lib.ivf_conv3d_pack_bwd_elems(cout, cinp, *k, *s, *[p[0] for p in pads], mm), device='cuda')
+    geom = L.BwdGeom()
+    L.check(lib.ivf_conv3d_pack_bwd(L.ptr(wd), L.ptr(scd), L.ptr(wb), cout, cin, cinp, *k, *s, *[p[0] for p in pads], mm,
+                                    ctypes.byref(geom), L.stream()))
+    assert geom.d2s == 1
+    e = L.ConvDesc()
+    e.B, e.Ti, e.Hi, e.Wi = B, *outs
+    e.Cin, e.in_ld, e.in_coff = cout, cout, 0
+    e.kT, e.kH, e.kW = geom.kT, geom.kH, geom.kW
+    e.sT = e.sH = e.sW = 1
+    e.pT, e.pH, e.pW = geom.pT, geom.pH, geom.pW
+    e.out_ld, e.out_coff = cinp, 0
+    e.math = mm
+    e.d2s = 1
+    e.bsT, e.bsH, e.bsW = s
+    e.To, e.Ho, e.Wo = [-(-n // ss) for n, ss in zip(thw, s)]
+    e.Cout = geom.rows
+    e.dT, e.dH, e.dW = thw
+    e.dC = cinp
+    n = lib.ivf_conv3d_variants(ctypes.byref(e), ids, 96)
+    assert n >= 3 and all(v >= 16 for v in list(ids)[:n])          # LDS-halo variants only
+    gcl = gy.cuda().contiguous()
+    ran = 0
+    for v in list(ids)[:n]:
+        e.variant = v
+        dxcl = torch.full((B,) + thw + (cinp,), float('nan'), device='cuda')
+        if lib.ivf_conv3d(ctypes.byref(e), L.ptr(gcl), L.ptr(wb), None, None, None, L.ptr(dxcl), L.stream()) != 0:
+            continue
+        ran += 1
+        assert rel_err(from_cl(dxcl, cin).double().cpu().numpy(), dx_ref.numpy()) < 1e-4, f"variant {v}"
+    assert ran >= 3
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16x6"])
+def test_every_stem_backward_variant_matches_torch(math):
+    """The depth-to-space (stride-2 backward-data) epilogue through EVERY variant the tuner may pick for the stem
+    (the 7x7x7 / stride-2 unit as a 4x4x4 block conv over dY), against torch fp64 autograd."""
+    import torch.nn.functional as F
+    import ivf_arch as arch
+    import ivf_lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(21)
+    B, cin, cinp, cout, k, s, thw = 2, 3, 4, 64, (7, 7, 7), (2, 2, 2), (7, 30, 35)     # odd sizes: partial blocks
+    w = torch.randn((cout, cin) + k, generator=gen) * 0.02
+    scale = torch.rand(cout, generator=gen) + 0.5
+    pads = [arch.same_pad(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip(thw, k, s)]
+    xp = torch.zeros((B, cin) + tuple(n + p[0] + p[1] for n, p in zip(thw, pads)), dtype=torch.float64, requires_grad=True)
+    gy = torch.randn((B, cout) + tuple(outs), generator=gen)
+    (F.conv3d(xp, w.double(), stride=s) * scale.double().view(1, -1, 1, 1, 1) * gy.double()).sum().backward()
+    dx_ref = xp.grad[:, :, pads[0][0]:pads[0][0] + thw[0], pads[1][0]:pads[1][0] + thw[1], pads[2][0]:pads[2][0] + thw[2]]
+    mm = L.MATH_MODES[math]
+    wd, scd = w.cuda(), scale.cuda()
+    wb = torch.empty(lib.ivf_conv3d_pack_bwd_elems(cout, cinp, *k, *s, *[p[0] for p in pads], mm), device='cuda')
+    geom = L.BwdGeom()
+    L.check(lib.ivf_conv3d_pack_bwd(L.ptr(wd), L.ptr(scd), L.ptr(wb), cout, cin, cinp, *k, *s, *[p[0] for p in pads], mm,
+                                    ctypes.byref(geom), L.stream()))
+    e = L.ConvDesc()
+    e.B, e.Ti, e.Hi, e.Wi = B, *outs
+    e.Cin, e.in_ld, e.in_coff = cout, cout, 0
+    e.kT, e.kH, e.kW = geom.kT, geom.kH, geom.kW
+    e.sT = e.sH = e.sW = 1
+    e.pT, e.pH, e.pW = geom.pT, geom.pH, geom.pW
+    e.out_ld, e.out_coff = cinp, 0
+    e.math = mm
+    e.d2s = 1
+    e.bsT, e.bsH, e.bsW = s
+    e.To, e.Ho, e.Wo = [-(-n // ss) for n, ss in zip(thw, s)]
+    e.Cout = geom.rows
+    e.dT, e.dH, e.dW = thw
+    e.dC = cinp
+    ids = (ctypes.c_int * 96)()
+    n = lib.ivf_conv3d_variants(ctypes.byref(e), ids, 96)
+    gcl = to_cl(gy.cuda())
+    ran = 0
+    for v in list(ids)[:n]:
+        e.variant = v
+        dxcl = torch.full((B,) + thw + (cinp,), float('nan'), device='cuda')
+        if lib.ivf_conv3d(ctypes.byref(e), L.ptr(gcl), L.ptr(wb), None, None, None, L.ptr(dxcl), L.stream()) != 0:
+            continue
+        ran += 1
+        assert rel_err(from_cl(dxcl, cin).double().cpu().numpy(), dx_ref.numpy()) < (1e-4 if math == "bf16x3" else 1e-5), \
+            f"variant {v}"
+    assert ran >= 8
