@@ -12,6 +12,7 @@
 // (BN x 32) streams per tap, double-buffered so its loads fly under the previous tap's MFMAs
 // (one barrier per tap).  Input bytes per MAC drop ~8x for 3x3x3.
 #pragma once
+#include <algorithm>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -577,11 +578,11 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
   constexpr int ROWB = (BKH + 8) * 2;
   constexpr int ROWB_B = DMA ? BKH * 2 : ROWB;
   const int HR = (TT + a.kT - 1) * halo_plane_rows<TT, TH, TW>(TH + a.kH - 1, TW + a.kW - 1);
-  const size_t shm = (size_t)NPA * HR * ROWB + (size_t)2 * TPS * KS * NPB * BN * ROWB_B + (size_t)HR * sizeof(int);
-  if (KS == 2 && (size_t)TT * TH * TW * BN * 4 > (size_t)NPA * HR * ROWB) {
-    set_error("conv3d_halo: tap-split reduction buffer does not fit the halo area");
-    return IVF_ERR_UNSUPPORTED;
-  }
+  size_t shm = (size_t)NPA * HR * ROWB + (size_t)2 * TPS * KS * NPB * BN * ROWB_B + (size_t)HR * sizeof(int);
+  // buffers that reuse the LDS from offset 0 once the tap loops are done (everything staged is dead by then): the
+  // tap-split reduction [BM][BN] floats, the depth-to-space tile [2 TT][16][16][4] floats
+  if (KS == 2) shm = std::max(shm, (size_t)TT * TH * TW * BN * 4);
+  if (a.d2s) shm = std::max(shm, (size_t)2 * TT * 256 * 4 * sizeof(float));
   if (shm > 160 * 1024) {
     set_error("conv3d_halo: %zu bytes of LDS needed", shm);
     return IVF_ERR_UNSUPPORTED;

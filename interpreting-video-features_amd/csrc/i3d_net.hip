@@ -74,7 +74,7 @@ struct Op {
   // backward bookkeeping for grad(src)
   bool bwd_accumulate = false, bwd_mask = false;
   // Inception module this op belongs to (-1: trunk) and whether it runs on the side stream: the HBM-bound branch
-  // (b0 forward; the 3x3x3 pool and b3b both ways) overlaps the MFMA-bound 3x3x3 convs of the other branches
+  // (the 3x3x3 pool and b3b, both ways) overlaps the MFMA-bound 3x3x3 convs of the other branches
   int module = -1;
   bool side_fwd = false, side_bwd = false;
 };
@@ -499,12 +499,17 @@ struct SideLane {
       }
     }
   }
-  hipStream_t side() {   // stream for a side-lane op (forks on first use inside a module)
+  // Fork at MODULE ENTRY: the side branch depends on the module input only, so the event is recorded before the
+  // first main-lane op of the module is enqueued (recorded at the first side op it would sit behind b1b / b2b, which
+  // come earlier in forward op order, and nothing would overlap).
+  void fork() {
+    if (!enabled || forked) return;
+    if (hipEventRecord(n->ev_fork, main) != hipSuccess || hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) rc = IVF_ERR_HIP;
+    forked = true;
+  }
+  hipStream_t side() {   // stream for a side-lane op
     if (!enabled) return main;
-    if (!forked) {
-      if (hipEventRecord(n->ev_fork, main) != hipSuccess || hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) rc = IVF_ERR_HIP;
-      forked = true;
-    }
+    fork();
     return n->side;
   }
   void join() {
@@ -522,6 +527,7 @@ static int run_forward(ivf_i3d* n, int b, float* logits, float* probs, hipStream
     if (o.module != module) {   // the module input must be complete: wait for the previous module's side branch
       lane.join();
       module = o.module;
+      if (module >= 0) lane.fork();
     }
     if (o.fwd_skip) continue;
     hipStream_t st = o.side_fwd ? lane.side() : s;
@@ -577,6 +583,7 @@ static int run_backward(ivf_i3d* n, int b, const int* target, const float* dout,
     if (o.module != module) {   // grad(module output) must be complete
       lane.join();
       module = o.module;
+      if (module >= 0) lane.fork();
     }
     if (n->cam_buf >= 0 && o.dst == n->cam_buf) break;   // Grad-CAM pass: the target's gradient is complete
     if (o.bwd_skip) continue;

@@ -89,15 +89,20 @@ def _cpu_module_with_gpu_gates(eng, sd, acts, name, v, flips):
         flips[1] += gate.numel()
         return pre * gate.to(pre.dtype)
 
+    def stored(t):
+        """what the next unit reads back: the fp32 value, or (bf16 activation storage) its RNE to bf16 -- applied
+        to the module's INNER buffers, with a straight-through gradient"""
+        return t + (t.bfloat16().float() - t).detach() if eng.math == "bf16act" else t
+
     if name in arch.INCEPTION:
         out_gate = acts[name] > 0
         inner_gate = eng.endpoint(name + '.b12a', 1).cpu() > 0
         c = [sd[f'{name}.{u}.conv3d.weight'].shape[0] for u in ('b0', 'b1a', 'b1b', 'b2a', 'b2b', 'b3b')]
         o1, o2, o3 = c[0], c[0] + c[2], c[0] + c[2] + c[4]
         b0 = gated(i3d_ref.unit3d(v, sd, name + '.b0', relu=False), out_gate[:, :o1])
-        t1 = gated(i3d_ref.unit3d(v, sd, name + '.b1a', relu=False), inner_gate[:, :c[1]])
+        t1 = stored(gated(i3d_ref.unit3d(v, sd, name + '.b1a', relu=False), inner_gate[:, :c[1]]))
         b1 = gated(i3d_ref.unit3d(t1, sd, name + '.b1b', relu=False), out_gate[:, o1:o2])
-        t2 = gated(i3d_ref.unit3d(v, sd, name + '.b2a', relu=False), inner_gate[:, c[1]:])
+        t2 = stored(gated(i3d_ref.unit3d(v, sd, name + '.b2a', relu=False), inner_gate[:, c[1]:]))
         b2 = gated(i3d_ref.unit3d(t2, sd, name + '.b2b', relu=False), out_gate[:, o2:o3])
         b3 = gated(i3d_ref.unit3d(i3d_ref.maxpool_same(v, (3, 3, 3), (1, 1, 1)), sd, name + '.b3b', relu=False),
                    out_gate[:, o3:])
@@ -119,7 +124,8 @@ def _modulewise_backward(eng, sd_np, shape, pool_kernel, gates=None):
     own: the CPU's recomputed gates against the GPU's, a handful per half million.)"""
     # element-level threshold (x max |reference gradient| of the tensor): the fp32 MFMA chain and the 6-pass split
     # round like fp32; the 3-pass split carries ~2^-17 per product
-    thr, fwd_tol, l2_tol = (2e-5, 1e-5, 1e-5) if eng.math in EXACT else (1e-3, 1e-4, 1e-3)
+    # (measured, profiles/r03_parity_measured.txt: 1.6e-6 / 6.4e-6 element error, 9e-7 / 5.8e-6 L2)
+    thr, fwd_tol, l2_tol = (1e-5, 1e-5, 5e-6) if eng.math in EXACT else (5e-5, 1e-4, 3e-5)
     flip_tol = 1e-4
     if gates is not None:
         thr, fwd_tol, l2_tol, flip_tol = gates
@@ -466,7 +472,7 @@ def test_bf16_activation_mode_modulewise():
     eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=1, softmax=True, math="bf16act")
     sd = R.i3d_state_dict(num_classes=174)
     eng.load_state_dict(sd)
-    #        element thr (x max), forward max-rel, L2, gate-flip fraction (bf16 values: a gate can sit ON zero)
+    #        element thr (x max), forward max-rel (one bf16 ulp of the largest element = 2^-8), L2, gate-flip fraction
     _modulewise_backward(eng, sd, (3, 16, 224, 224), (2, 7, 7), gates=(2e-2, 4e-3, 5e-3, 1e-3))
 
 
@@ -632,16 +638,18 @@ def test_gradcam_other_target_layers(s16, layer, golden):
     ok = ~np.isnan(ref)
     err = float(np.max(np.abs(got[ok] - ref[ok])))
     note(f"gradcam s16 target {layer} {s16.math}: max|d| {err:.2e}, mean|d| {np.mean(np.abs(got[ok] - ref[ok])):.2e}")
-    # 1e-3 (north_star) wherever two CPU runs of the reference agree that well; further down, the map inherits the
-    # sensitivity of the gradient to max-pool near-ties / ReLU zeros, and the gate is 3x what the reference's own map
-    # moves between fp32 and fp64 (or another thread count) on the CPU: tests/golden/gradcam_spread.npz
-    # (make_golden.py gen_gradcam_spread; Conv3d_2c 7.5e-4, MaxPool3d_3a 1.3e-3, Mixed_3c 3.1e-4, Mixed_4e 3.8e-6).
-    # The arithmetic itself is checked without that sensitivity in test_gradcam_deep_targets_modulewise.
+    # 1e-3 (north_star) where at most one strided max-pool lies between the target and the score.  Further down the
+    # plain comparison measures which max-pool near-ties / ReLU zeros two fp32 runs break which way, not arithmetic:
+    #  * the reference ITSELF moves by 1e-4 .. 1.3e-3 on these targets between fp32 and fp64 / another thread count
+    #    (tests/golden/gradcam_spread.npz, make_golden.py gen_gradcam_spread; recorded in the note below);
+    #  * with the ties and gates pinned (test_gradcam_deep_targets_modulewise: CPU chain on the GPU's activations and
+    #    gates) the same maps agree to 3.5e-6 (fp32) / 1.7e-4 (6-pass split) / 1.0e-4 (3-pass split) -- THAT test
+    #    carries the 1e-3 gate for the deep targets; this one bounds the tie sensitivity (sanity: 1e-2 / 3e-2).
     sp = golden('gradcam_spread')
     floor = max(float(sp[f'{layer}_f64_dmax']), float(sp[f'{layer}_f32t3_dmax']))
-    gate = max(1e-3, 3 * floor) if s16.math in EXACT else max(1e-3, 3 * floor, 3e-2 if floor > 1e-4 else 1e-3)
-    note(f"gradcam s16 target {layer}: CPU-vs-CPU floor {floor:.2e}, gate {gate:.2e}")
-    assert ok.any() and err < gate
+    note(f"gradcam s16 target {layer}: the reference's own fp64 / other-thread-count runs differ from its committed map by {floor:.2e}")
+    deep = layer not in ('Mixed_4f', 'Mixed_5b', 'Mixed_5c')
+    assert ok.any() and err < ((1e-2 if s16.math in EXACT else 3e-2) if deep else 1e-3)
     # the ordinary passes are untouched by the ungated Grad-CAM pass before them
     p2 = s16.forward(x)
     assert torch.equal(p2, probs)

@@ -13,7 +13,8 @@ if os.path.exists(log):
     os.remove(log)
 os.environ["IVF_TUNE_LOG"] = log
 import ivf_engine, ivf_recipe as R   # noqa: E402
-eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=B, softmax=True)
+math = sys.argv[3] if len(sys.argv) > 3 else None       # arithmetic mode (default: ivf_engine.DEFAULT_MATH)
+eng = ivf_engine.I3DEngine(174, (3, 16, 224, 224), max_batch=B, softmax=True, math=math)
 eng.load_state_dict(R.i3d_state_dict(num_classes=174))
 fam = lambda v: "pix4" if v == 15 else "halo" if v >= 16 else "igemm"
 best = collections.OrderedDict()
