@@ -14,6 +14,7 @@
 // Layout is planar per frame ([.., C, H, W], W fastest): channel counts are 1..16, so
 // coalescing comes from W, and the reference's NCTHW clip is consumed in place.
 // Weights (a few KB) are staged in LDS by every block.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -186,6 +187,195 @@ __global__ __launch_bounds__(256) void clstm_step_fwd_split_kernel(
   sp[(long)(3 * hid + j) * plane] = co;
   sp[(long)(4 * hid + j) * plane] = cc;
   Hs[(((long)b * T + t) * hid + j) * plane + px] = ch;
+}
+
+// ---------------------------------------------------------------- persistent recurrence (hid <= 4)
+// The step kernels above pay, per time step, a launch, a trip of the hidden state through L2 and a bounds test per
+// tap.  For full batches the recurrence runs instead as ONE launch per layer and direction: a workgroup owns a whole
+// clip, keeps the hidden state (forward) / one gate group of dG (backward) as zero-bordered planes in LDS -- a 5x5 tap
+// is an LDS read at a constant offset, no bounds test -- carries c (forward) / dC (backward) in registers across the T
+// steps, and only streams what the other direction needs (gates, h, dG) through HBM.  Each thread owns the pixels
+// p = tid + q * blockDim; the taps run outermost over batches of 3-4 of them, so one scalar load of a tap's 16 weights
+// feeds 8 packed FMAs per pixel of the batch.  c / dC / dh live in the rows of the thread's own pixels (L1/L2-hot), so
+// every pixel loop stays rolled (one copy of the code, < 128 registers: 16 waves per clip).
+constexpr int SEQ_NT = 1024;   // threads per clip at most (16 waves: the rolled pixel loops need < 128 VGPRs)
+
+// Gate non-linearities of the persistent kernels: v_exp_f32 / v_rcp_f32 forms (about 2 ulp; tanh(x) = 2 sigmoid(2x) - 1
+// carries ~2e-7 absolute near zero).  libm's expf / tanhf expand to ~40-60 instructions each and 20 of them per pixel
+// cost as much as the 25-tap convolution itself; parity gates of the ConvLSTM path are 1e-3.
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float tanh_fast(float v) { return 2.f * sigmoid_fast(2.f * v) - 1.f; }
+
+template <int HID>
+__global__ __launch_bounds__(1024) void clstm_seq_fwd_kernel(
+    const float* __restrict__ gx, const float* __restrict__ whT, float* __restrict__ S, float* __restrict__ Hs,
+    int T, int k, int Ho, int Wo) {
+  extern __shared__ float hl[];   // [HID][Ho + 2 pad][Wo + 2 pad], borders stay zero
+  constexpr int G = 4 * HID;
+  constexpr int PB = 5;           // pixels per batch (the 60 x 80 map over 960 threads: 5 each): one scalar load of a tap's weights feeds 5 x 8 packed FMAs
+  const int pad = (k - 1) / 2;
+  const int WP = Wo + 2 * pad, HP = Ho + 2 * pad;
+  const int plane = Ho * Wo;
+  const int b = blockIdx.x;
+  const int NT = blockDim.x;
+  for (int i = threadIdx.x; i < HID * HP * WP; i += NT) hl[i] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* gp = gx + ((long)b * T + t) * G * plane;
+    float* sp = S + ((long)b * T + t) * 5 * HID * plane;
+    float* hp = Hs + ((long)b * T + t) * HID * plane;
+    // c[t-1] comes back from the saved state rows of the thread's own pixels (S is written anyway for the backward):
+    // no state registers, the batches are independent and the batch loop stays rolled (one copy of the code)
+    const float* cprev = t > 0 ? S + (((long)b * T + (t - 1)) * 5 + 4) * HID * plane : nullptr;
+#pragma unroll 1
+    for (int p0 = threadIdx.x; p0 < plane; p0 += PB * NT) {
+      int pix[PB], lds0[PB];
+      float acc[PB][G];
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        const int p = p0 + u * NT;
+        pix[u] = p < plane ? p : -1;
+        const int pc = p < plane ? p : 0;          // (lanes without a pixel compute on pixel 0 and store nothing)
+        lds0[u] = (pc / Wo) * WP + pc % Wo;
+#pragma unroll
+        for (int o = 0; o < G; ++o) acc[u][o] = gp[(long)o * plane + pc];
+      }
+      for (int c = 0; c < HID; ++c)
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) {
+            const float* wp = whT + ((c * k + ky) * k + kx) * 16;
+            const int off = (c * HP + ky) * WP + kx;
+            float v[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) v[u] = hl[lds0[u] + off];
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+              for (int o = 0; o < G; ++o) acc[u][o] = __builtin_fmaf(wp[o], v[u], acc[u][o]);
+          }
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        const int p = pix[u];
+        if (p < 0) continue;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) {
+          const float ci = sigmoid_fast(acc[u][j]), cf = sigmoid_fast(acc[u][HID + j]);
+          const float cg = tanh_fast(acc[u][2 * HID + j]), co = sigmoid_fast(acc[u][3 * HID + j]);
+          const float cp = cprev ? cprev[(long)j * plane + p] : 0.f;
+          const float cc = cf * cp + ci * cg;
+          const float ch = co * tanh_fast(cc);
+          sp[(long)(0 * HID + j) * plane + p] = ci;
+          sp[(long)(1 * HID + j) * plane + p] = cf;
+          sp[(long)(2 * HID + j) * plane + p] = cg;
+          sp[(long)(3 * HID + j) * plane + p] = co;
+          sp[(long)(4 * HID + j) * plane + p] = cc;
+          hp[(long)j * plane + p] = ch;
+        }
+      }
+    }
+    __syncthreads();      // every read of h[t-1] is done
+    // h[t] of the thread's OWN pixels back from the rows it has just written
+    for (int p = threadIdx.x; p < plane; p += NT) {
+      const int l = (p / Wo + pad) * WP + p % Wo + pad;
+#pragma unroll
+      for (int j = 0; j < HID; ++j) hl[j * HP * WP + l] = hp[(long)j * plane + p];
+    }
+    __syncthreads();
+  }
+}
+
+// BPTT of the same: dG[t] for all T steps in one launch.  Per step the hidden-state convolution of dG[t+1] runs
+// gate group by gate group (the hid planes of one gate type in LDS at a time: all 16 planes of the layer's first map
+// would not fit); dh[t] accumulates in the dHpool rows of the thread's own pixels (L1/L2-hot, not read by anyone else),
+// so every loop over pixels stays rolled; the gate derivatives follow from the saved gates; dC goes through the layer's
+// dC rows (own pixels).
+template <int HID>
+__global__ __launch_bounds__(1024) void clstm_seq_bwd_kernel(
+    float* __restrict__ dHpool, const float* __restrict__ whB, const float* __restrict__ S,
+    float* __restrict__ dG, float* __restrict__ dC, int T, int k, int Ho, int Wo) {
+  extern __shared__ float gl[];   // [HID][Ho + 2 pad][Wo + 2 pad]: one gate group of dG[t+1], zero borders
+  constexpr int G = 4 * HID;
+  constexpr int PB = 5;
+  const int pad = (k - 1) / 2;
+  const int WP = Wo + 2 * pad, HP = Ho + 2 * pad;
+  const int plane = Ho * Wo;
+  const int b = blockIdx.x;
+  const int NT = blockDim.x;
+  for (int i = threadIdx.x; i < HID * HP * WP; i += NT) gl[i] = 0.f;
+  float* dcp = dC + (long)b * HID * plane;
+  for (int t = T - 1; t >= 0; --t) {
+    float* dhrow = dHpool + ((long)b * T + t) * HID * plane;
+    if (t + 1 < T) {
+      const float* gnext = dG + ((long)b * T + (t + 1)) * G * plane;
+      for (int g = 0; g < 4; ++g) {
+        __syncthreads();      // the previous group's taps are done
+        // (this step's group rows of the thread's OWN pixels, written by itself one step ago: program order is enough)
+        for (int p = threadIdx.x; p < plane; p += NT) {
+          const int l = (p / Wo + pad) * WP + p % Wo + pad;
+#pragma unroll
+          for (int jj = 0; jj < HID; ++jj) gl[jj * HP * WP + l] = gnext[(long)(g * HID + jj) * plane + p];
+        }
+        __syncthreads();
+        // dh[j] += sum_{ky,kx,jj} whB[ky][kx][g*hid+jj][j] * dG[t+1][g*hid+jj][y - ky + pad][x - kx + pad]
+#pragma unroll 1
+        for (int p0 = threadIdx.x; p0 < plane; p0 += PB * NT) {
+          int pix[PB], lds0[PB];
+          float dh[PB][HID];
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            const int p = p0 + u * NT;
+            pix[u] = p < plane ? p : -1;
+            const int pc = p < plane ? p : 0;
+            lds0[u] = (pc / Wo) * WP + pc % Wo;
+#pragma unroll
+            for (int j = 0; j < HID; ++j) dh[u][j] = dhrow[(long)j * plane + pc];
+          }
+          for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+              const float* wp = whB + (ky * k + kx) * 64 + g * HID * 4;      // [jj][j], j padded to 4
+              const int off = (2 * pad - ky) * WP + (2 * pad - kx);
+#pragma unroll
+              for (int jj = 0; jj < HID; ++jj) {
+                float v[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) v[u] = gl[jj * HP * WP + lds0[u] + off];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                  for (int j = 0; j < HID; ++j) dh[u][j] = __builtin_fmaf(wp[jj * 4 + j], v[u], dh[u][j]);
+              }
+            }
+#pragma unroll
+          for (int u = 0; u < PB; ++u)
+            if (pix[u] >= 0)
+#pragma unroll
+              for (int j = 0; j < HID; ++j) dhrow[(long)j * plane + pix[u]] = dh[u][j];
+        }
+      }
+    }
+    const float* sp = S + ((long)b * T + t) * 5 * HID * plane;
+    const float* cprev = (t > 0) ? S + (((long)b * T + (t - 1)) * 5 + 4) * HID * plane : nullptr;
+    float* gout = dG + ((long)b * T + t) * G * plane;
+#pragma unroll 1
+    for (int p = threadIdx.x; p < plane; p += NT) {
+#pragma unroll 1
+      for (int j = 0; j < HID; ++j) {
+        const float dhj = dhrow[(long)j * plane + p];
+        const float ci = sp[(long)(0 * HID + j) * plane + p], cf = sp[(long)(1 * HID + j) * plane + p];
+        const float cg = sp[(long)(2 * HID + j) * plane + p], co = sp[(long)(3 * HID + j) * plane + p];
+        const float cc = sp[(long)(4 * HID + j) * plane + p];
+        const float cp = cprev ? cprev[(long)j * plane + p] : 0.f;
+        const float th = tanh_fast(cc);
+        const float dco = dhj * th;
+        const float dcc = dhj * co * (1.f - th * th) + ((t + 1 < T) ? dcp[(long)j * plane + p] : 0.f);
+        gout[(long)(0 * HID + j) * plane + p] = dcc * cg * (ci * (1.f - ci));
+        gout[(long)(1 * HID + j) * plane + p] = dcc * cp * (cf * (1.f - cf));
+        gout[(long)(2 * HID + j) * plane + p] = dcc * ci * (1.f - cg * cg);
+        gout[(long)(3 * HID + j) * plane + p] = dco * (co * (1.f - co));
+        dcp[(long)j * plane + p] = dcc * cf;
+      }
+    }
+  }
 }
 
 // X[b,t,j,yp,xp] = max over 2x2 of (scale[j]*H + shift[j]); first strict maximum wins
@@ -903,6 +1093,25 @@ extern "C" int ivf_clstm_load_head(ivf_clstm_t* n, const float* bn_gamma, const 
 
 namespace ivf {
 
+// The persistent recurrence (clstm_seq_*_kernel): hid <= 4, the clip's map within SEQ_MAXP pixels per thread and its
+// padded planes within the LDS; chosen for batches that fill the chip with one workgroup per clip
+// (IVF_CLSTM_PERSIST=1 always / 0 never: tests and A/B measurements).
+static size_t seq_lds_bytes(const LayerPlan& p, const ivf_clstm_config& c) {
+  const int pad = (c.kernel - 1) / 2;
+  return (size_t)c.hidden * (p.Ho + 2 * pad) * (p.Wo + 2 * pad) * sizeof(float);
+}
+static int seq_threads(const LayerPlan& p) {
+  const int plane = p.Ho * p.Wo;
+  const int per = (plane + SEQ_NT - 1) / SEQ_NT;         // pixels per thread
+  return std::min(SEQ_NT, ((plane + per - 1) / per + 63) / 64 * 64);
+}
+static bool seq_ok(const LayerPlan& p, const ivf_clstm_config& c, int b) {
+  static const int mode = getenv("IVF_CLSTM_PERSIST") ? atoi(getenv("IVF_CLSTM_PERSIST")) : -1;
+  if (mode == 0 || c.hidden > 4) return false;
+  if (seq_lds_bytes(p, c) > 160 * 1024) return false;
+  return mode == 1 || b >= 64;
+}
+
 static int clstm_ready(const ivf_clstm* n, int b) {
   IVF_CHECK_ARG(n && n->wa && n->ws, "clstm: not bound");
   IVF_CHECK_ARG(b > 0 && b <= n->cfg.B, "clstm: batch %d outside [1,%d]", b, n->cfg.B);
@@ -938,6 +1147,23 @@ static int clstm_run_forward(ivf_clstm* n, const float* x, int b, float* logits,
                          n->wa + p.wxT_off, n->wa + p.bx_off, n->wsf(p.gx_off), b, T, p.cin, p.Hin, p.Win, sB, sC, sT,
                          hid, k, c.stride, p.Ho, p.Wo);
     IVF_CHECK_LAUNCH();
+    if (seq_ok(p, c, b)) {       // the whole recurrence of the layer in one launch, one workgroup per clip
+#define IVF_SEQ_F(HH)                                                                                                   \
+  {                                                                                                                      \
+    static LdsAttrOnce once;                                                                                             \
+    IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&clstm_seq_fwd_kernel<HH>), 160 * 1024, once));          \
+    hipLaunchKernelGGL(clstm_seq_fwd_kernel<HH>, dim3(b), dim3(seq_threads(p)), seq_lds_bytes(p, c), s, n->wsf(p.gx_off), \
+                       n->wa + p.whT_off, n->wsf(p.S_off), n->wsf(p.H_off), T, k, p.Ho, p.Wo);                          \
+  }
+      switch (hid) {
+        case 1: IVF_SEQ_F(1) break;
+        case 2: IVF_SEQ_F(2) break;
+        case 3: IVF_SEQ_F(3) break;
+        default: IVF_SEQ_F(4) break;
+      }
+#undef IVF_SEQ_F
+      IVF_CHECK_LAUNCH();
+    } else
     for (int t = 0; t < T; ++t) {
       if (hid > 4) {
         hipLaunchKernelGGL(clstm_step_fwd_wide_kernel, dim3(grid_for((long)b * p.Ho * p.Wo, 256, 16384), hid / 4),
@@ -1005,6 +1231,23 @@ static int clstm_run_backward(ivf_clstm* n, int b, const int* target, const floa
                        n->wsf(p.dX_off), n->at<unsigned char>(p.arg_off), sc, n->wsf(p.dHp_off), (long)b * T, hid,
                        p.Ho, p.Wo, p.Hp, p.Wp);
     IVF_CHECK_LAUNCH();
+    if (seq_ok(p, c, b)) {
+#define IVF_SEQ_B(HH)                                                                                                     \
+  {                                                                                                                        \
+    static LdsAttrOnce once;                                                                                               \
+    IVF_PROPAGATE(raise_lds_limit(reinterpret_cast<const void*>(&clstm_seq_bwd_kernel<HH>), 160 * 1024, once));            \
+    hipLaunchKernelGGL(clstm_seq_bwd_kernel<HH>, dim3(b), dim3(seq_threads(p)), seq_lds_bytes(p, c), s, n->wsf(p.dHp_off), \
+                       n->wa + p.whB_off, n->wsf(p.S_off), n->wsf(p.dG_off), n->wsf(p.dC_off), T, k, p.Ho, p.Wo);        \
+  }
+      switch (hid) {
+        case 1: IVF_SEQ_B(1) break;
+        case 2: IVF_SEQ_B(2) break;
+        case 3: IVF_SEQ_B(3) break;
+        default: IVF_SEQ_B(4) break;
+      }
+#undef IVF_SEQ_B
+      IVF_CHECK_LAUNCH();
+    } else
     for (int t = T - 1; t >= 0; --t) {
       static const int split_below = getenv("IVF_CLSTM_SPLIT") ? atoi(getenv("IVF_CLSTM_SPLIT")) : (1 << 30);
       if (hid > 4) {

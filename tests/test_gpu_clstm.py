@@ -219,3 +219,36 @@ def test_clstm_use_entire_seq(golden):
                        image_size=(160, 120), conv_stride=2, effective_step=[7, 15, 23, 31], use_entire_seq=True)
     with pytest.raises(RuntimeError):          # the reference's .view fails when effective steps lie past `step`
         m2.cuda().eval()(torch.zeros(1, 3, 16, 120, 160).cuda())
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_clstm_persistent_recurrence_matches_stepwise_and_reference(C, golden):
+    """Batches of 64+ clips run each layer's recurrence as ONE persistent launch per direction (a workgroup per clip,
+    hidden state / dG gate groups in LDS: clstm_seq_fwd/bwd_kernel) instead of one launch per time step.  Same clips
+    through both forms (rows are independent): logits, probabilities and the input gradient agree to fp32 rounding,
+    and the persistent form meets the reference fixture on its own."""
+    import ivf_recipe as R
+    g = golden('clstm')
+    base = np.stack([R.clip(3, C, 32, 120, 160), R.clip(4, C, 32, 120, 160)]) / 255.0
+    small = _engine(C, B=2)                       # stepwise kernels (batch below the persistent threshold)
+    xs = torch.from_numpy(base).float().cuda()
+    ps, ls = small.forward(xs, want_logits=True)
+    dout = torch.zeros(2, 6, device='cuda')
+    dout[0, 2] = 1
+    dout[1, 4] = 1
+    _, dxs = small.backward(2, dout=dout)
+    B = 64
+    big = _engine(C, B=B)                         # persistent kernels
+    xb = torch.from_numpy(np.concatenate([base] * (B // 2))).float().cuda()
+    pb, lb = big.forward(xb, want_logits=True)
+    _, dxb = big.backward(B, dout=dout.repeat(B // 2, 1))
+    for r in (0, 1, B - 2, B - 1):
+        assert rel_err(lb[r].cpu().numpy(), ls[r % 2].cpu().numpy()) < 1e-4      # (v_exp_f32 gate functions in the persistent form)
+        assert rel_err(pb[r].cpu().numpy(), ps[r % 2].cpu().numpy()) < 1e-4
+        assert rel_err(dxb[r].cpu().numpy(), dxs[r % 2].cpu().numpy()) < 5e-4
+    assert rel_err(lb[:2].cpu().numpy(), g[f'c{C}_logits']) < 1e-3
+    assert rel_err(pb[:2].cpu().numpy(), g[f'c{C}_probs']) < 1e-3
+    dxn = dxb[:2].cpu().numpy()
+    assert rel_err(dxn.ravel()[g[f'c{C}_dx_idx']], g[f'c{C}_dx_val']) < 2e-3
+    note(f"clstm persistent vs stepwise (C={C}): logits {rel_err(lb[:2].cpu().numpy(), ls.cpu().numpy()):.2e}, "
+         f"dx {rel_err(dxb[:2].cpu().numpy(), dxs.cpu().numpy()):.2e}")

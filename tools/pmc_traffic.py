@@ -5,7 +5,7 @@
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d B -- python3 bench.py ...
     python tools/pmc_traffic.py A B <batch> out.json
 
-    python tools/pmc_traffic.py A B <batch> out.json [bench_line.json]
+    python tools/pmc_traffic.py A B <batch> out.json [bench_line.json] [math] [frames]
 
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (HBM
 section: gfx950 counts 128-byte requests as 64).  Only the launches of the search iterations
@@ -58,9 +58,30 @@ def stem_backward(folder, counter):
     return tot / max(n, 1), n, kern
 
 
+def stem_forward(folder, counter):
+    """The stem's forward launches of the search iterations: the FIRST conv3d_* dispatch after each freeze_fwd* /
+    reverse_fwd* dispatch (Conv3d_1a_7x7 is the first op of the plan)."""
+    f = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    tot, n, kern, armed = 0.0, 0, None, False
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if k.startswith("freeze_fwd") or k.startswith("reverse_fwd"):
+            armed = True
+        elif k.startswith("conv3d_") and armed:
+            tot += float(r["Counter_Value"])
+            n += 1
+            kern = k
+            armed = False
+    return tot / max(n, 1), n, kern
+
+
 def main():
     fa, fb, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     bench_line = sys.argv[5] if len(sys.argv) > 5 else None
+    math = sys.argv[6] if len(sys.argv) > 6 else "bf16x6"
+    frames = int(sys.argv[7]) if len(sys.argv) > 7 else 16
     fetch, write = per_kernel(fa, "FETCH_SIZE"), per_kernel(fb, "WRITE_SIZE")
     kernels = {}
     for k in fetch:
@@ -89,8 +110,16 @@ def main():
             "kernel": kf, "launches": nf, "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024),
             "fetch_kb_raw_per_launch": int(fkb), "write_kb_per_launch": int(wkb),
             "found_as": "last conv3d_* dispatch before each freeze_bwd* dispatch"}
-    doc = {"sites": sites, "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
-                  "command (split-bf16); launches from the first search iteration on (after autotune); "
+    fkb, nf, kf = stem_forward(fa, "FETCH_SIZE")
+    wkb, nw, kw = stem_forward(fb, "WRITE_SIZE")
+    if nf and nw and kf == kw:
+        sites["Conv3d_1a_7x7 forward"] = {
+            "kernel": kf, "launches": nf, "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024),
+            "fetch_kb_raw_per_launch": int(fkb), "write_kb_per_launch": int(wkb),
+            "found_as": "first conv3d_* dispatch after each freeze_fwd* / reverse_fwd* dispatch"}
+    doc = {"sites": sites, "math": math, "frames": frames,
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of the same short bench.py "
+                  "command; launches from the first search iteration on (after autotune); "
                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM "
                   "(gfx950 counts 128-B requests at 64 B)",
            "batch": batch, "total_hbm_bytes_counted": total,
