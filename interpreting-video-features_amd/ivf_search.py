@@ -108,7 +108,9 @@ class MaskSearch:
             out["init_mask"] = raw.clone()
             traj, _ = eng.search(x, target, raw, self.lam1, self.lam2, self.n_iter, lr=self.lr,
                                  want_traj=True, mode=self.mask_type)        # smth:191-214
-            mask = torch.sigmoid(raw)                                        # smth:216
+            mask = torch.empty_like(raw)                                     # smth:216, with the sigmoid the loop itself uses
+            with torch.cuda.device(dev):
+                L.check(L.lib().ivf_sigmoid(L.ptr(raw), L.ptr(mask), raw.numel(), L.stream()))
             out["time_mask"] = mask
             out["freeze_score"] = traj[-1, :, 3] if self.n_iter > 0 else torch.full((b,), float("nan"), device=dev)
             rev = eng.perturbed_forward(x, mask, "reverse")                  # smth:234-235
