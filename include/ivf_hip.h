@@ -469,6 +469,64 @@ int ivf_viz_blend(const float* clip, const float* cam, const float* perturbed, c
 int ivf_viz_dots(unsigned char* img, const float* mask_snapped, int T, int H, int W3, int image_width,
                  int image_height, ivf_stream_t stream);
 
+/* ------------------------------------------------------------------ TF-style ConvLSTM search variant
+ *
+ * DOCUMENTED EXTENSION, PARITY UNPINNED: the reference's TensorFlow half (video_features_tf/mask/find_mask_kth.py:300-372,
+ * 431-452; mask/gradcam.py:28-111; models/clstm.py:9-52, 87-126) runs the temporal-mask search and a per-frame
+ * Grad-CAM over a Keras ConvLSTM2D stack.  TF 1.12 / Keras cannot be installed where this library is built, so no
+ * output of that code pins these entry points; they follow the published Keras ConvLSTM2D definition as the call site
+ * configures it (csrc/tf_clstm.hip has the equations): x-part conv with `padding` 'valid' | 'same' (TensorFlow rule)
+ * and `stride`, recurrent conv 'same' / stride 1, kernel kh x kw (any, e.g. the configs' 3 x 5), gate order i, f, c, o,
+ * hard-sigmoid recurrent activation (TF 1.12 default), MaxPooling2D(2x2) per frame after every layer, no batch norm
+ * (find_mask_kth.py:331), dense head over the flattened (NHWC) last element or whole sequence.
+ * Weights in Keras layouts: kernel [kh][kw][Cin][4F], recurrent_kernel [kh][kw][F][4F], bias [4F], dense kernel
+ * [inputs][classes].  Clips are NCTHW like everywhere else in this library. */
+typedef struct {
+  int B;                      /* maximum clips per call */
+  int C, T, H, W;             /* clip geometry */
+  int layers;                 /* ConvLSTM2D blocks (<= 8) */
+  int units[8];               /* filters per block (FLAGS.layers) */
+  int kh, kw;                 /* kernel_size_1, kernel_size_2 */
+  int stride;                 /* FLAGS.strides */
+  int padding;                /* 0 'valid', 1 'same' */
+  int recurrent_hard_sigmoid; /* 1: hard_sigmoid (TF 1.12 Keras default), 0: sigmoid */
+  int only_last;              /* only_last_element_for_fc == 'yes' */
+  int num_classes;
+} ivf_tfclstm_config;
+
+typedef struct ivf_tfclstm ivf_tfclstm_t;
+
+int ivf_tfclstm_create(const ivf_tfclstm_config* cfg, ivf_tfclstm_t** out);
+void ivf_tfclstm_destroy(ivf_tfclstm_t* net);
+size_t ivf_tfclstm_weights_bytes(const ivf_tfclstm_t* net);
+size_t ivf_tfclstm_workspace_bytes(const ivf_tfclstm_t* net);
+int ivf_tfclstm_bind(ivf_tfclstm_t* net, void* weights_arena, void* workspace);
+/* conv output (Ho, Wo), pooled (Hp, Wp) and filters of a block; inputs of the dense head */
+int ivf_tfclstm_layer_dims(const ivf_tfclstm_t* net, int layer, int* Ho, int* Wo, int* Hp, int* Wp, int* units);
+int ivf_tfclstm_fc_inputs(const ivf_tfclstm_t* net);
+int ivf_tfclstm_load_layer(ivf_tfclstm_t* net, int layer, const float* kernel, const float* recurrent_kernel,
+                           const float* bias, ivf_stream_t stream);
+int ivf_tfclstm_load_head(ivf_tfclstm_t* net, const float* dense_kernel, const float* dense_bias, ivf_stream_t stream);
+/* clstm.clstm(x) + softmax (find_mask_kth.py:331-332): logits / probs [b,K] (either may be NULL) */
+int ivf_tfclstm_forward(ivf_tfclstm_t* net, const float* x, int b, float* logits, float* probs, ivf_stream_t stream);
+/* BPTT of probs[b, target[b]] to the clip: score [b] optional, dx NCTHW */
+int ivf_tfclstm_backward(ivf_tfclstm_t* net, int b, const int* target, float* score, float* dx, ivf_stream_t stream);
+/* the tf.scan freeze recurrence (find_mask_kth.py:318-327) with mask [b,T] AS GIVEN, then the model: probs [b,K].
+ * (The TF graph always applies sigmoid to its mask variable, also in init_mask and in the baseline prediction: callers
+ * that mimic it pass sigmoid(values).) */
+int ivf_tfclstm_perturbed_forward(ivf_tfclstm_t* net, const float* x, int b, const float* mask, float* probs,
+                                  ivf_stream_t stream);
+/* N iterations of the search (find_mask_kth.py:356-372, 431-452) on the device; tf.train.AdamOptimizer's update
+ * (epsilon beside sqrt(v) before the bias correction); traj [N,b,4] = (loss, l1, tv, score) or NULL */
+int ivf_tfclstm_search(ivf_tfclstm_t* net, const float* x, int b, const int* target, float* raw_mask, float* exp_avg,
+                       float* exp_avg_sq, float lam1, float lam2, float lr, float beta1, float beta2, float eps, int N,
+                       int first_step, float* traj, ivf_stream_t stream);
+/* mask/gradcam.py:28-111: per-frame Grad-CAM on the last ConvLSTM2D's output sequence from the class LOGIT;
+ * mask [b,T] as given to the freeze recurrence (NULL: unperturbed clip); per_frame 1 = normalization_mode 'frame',
+ * 0 = 'sequence'; cam [b,T,out_h,out_w] (bilinear resize restating skimage.transform.resize, unpinned) */
+int ivf_tfclstm_gradcam(ivf_tfclstm_t* net, const float* x, int b, const float* mask, const int* target, int per_frame,
+                        int out_h, int out_w, float* cam, float* probs, ivf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement */
 
 /* HIP-event timing of the convolution launches on their own stream, sampled on every

@@ -382,3 +382,136 @@ class CLSTMEngine:
         raise L.IvfError("Grad-CAM for the PyTorch ConvLSTM cannot run in the reference either "
                          "(grad-cam.py:33-49 refers to attributes CLSTM_4.Model lacks, SURVEY.md F5); "
                          "not built")
+
+
+class TFCLSTMEngine:
+    """SURVEY 8f N4, a DOCUMENTED EXTENSION (parity unpinned): the TF half's Keras ConvLSTM2D classifier
+    (video_features_tf/models/clstm.py:87-126) and its temporal-mask search / per-frame Grad-CAM
+    (mask/find_mask_kth.py:300-452, mask/gradcam.py:28-111) on libivf_hip's generic direct-convolution kernels
+    (csrc/tf_clstm.hip).  Clips are NCTHW like everywhere else; `from_tf_layout` converts [B,T,H,W,C]."""
+
+    def __init__(self, num_classes, clip_shape, units=(32, 32), kernel=(3, 5), stride=2, padding="valid",
+                 recurrent_activation="hard_sigmoid", only_last_element_for_fc=True, max_batch=1, device=None):
+        L.require_gpu()
+        self.device = torch.device(device if device is not None else "cuda")
+        C, T, H, W = clip_shape
+        cfg = L.TFCLSTMConfig()
+        cfg.B, cfg.C, cfg.T, cfg.H, cfg.W = int(max_batch), C, T, H, W
+        cfg.layers = len(units)
+        for i, u in enumerate(units):
+            cfg.units[i] = int(u)
+        cfg.kh, cfg.kw = int(kernel[0]), int(kernel[1])
+        cfg.stride = int(stride)
+        if padding not in ("valid", "same"):
+            raise L.IvfError("padding must be 'valid' or 'same'")
+        cfg.padding = 1 if padding == "same" else 0
+        if recurrent_activation not in ("hard_sigmoid", "sigmoid"):
+            raise L.IvfError("recurrent_activation must be 'hard_sigmoid' or 'sigmoid'")
+        cfg.recurrent_hard_sigmoid = 1 if recurrent_activation == "hard_sigmoid" else 0
+        cfg.only_last = 1 if only_last_element_for_fc else 0
+        cfg.num_classes = int(num_classes)
+        self.cfg, self.clip_shape, self.max_batch, self.K = cfg, (C, T, H, W), int(max_batch), int(num_classes)
+        self.units = tuple(int(u) for u in units)
+        self._h = c_void_p()
+        L.check(L.lib().ivf_tfclstm_create(byref(cfg), byref(self._h)))
+        with torch.cuda.device(self.device):
+            self._weights = _arena(L.lib().ivf_tfclstm_weights_bytes(self._h), self.device)
+            self._ws = _arena(L.lib().ivf_tfclstm_workspace_bytes(self._h), self.device)
+        L.check(L.lib().ivf_tfclstm_bind(self._h, L.ptr(self._weights), L.ptr(self._ws)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and L is not None and getattr(L, "_lib", None) is not None:
+            L._lib.ivf_tfclstm_destroy(h)
+            self._h = c_void_p()
+
+    @staticmethod
+    def from_tf_layout(x_bthwc):
+        """[B,T,H,W,C] (the TF graph's sequence layout) -> NCTHW."""
+        return x_bthwc.permute(0, 4, 1, 2, 3).contiguous()
+
+    @property
+    def fc_inputs(self):
+        return L.lib().ivf_tfclstm_fc_inputs(self._h)
+
+    def layer_dims(self, i):
+        v = [c_int() for _ in range(5)]
+        L.check(L.lib().ivf_tfclstm_layer_dims(self._h, i, *[byref(a) for a in v]))
+        return tuple(a.value for a in v)
+
+    def load_weights(self, layers, dense_w, dense_b):
+        """layers: [(kernel [kh,kw,Cin,4F], recurrent_kernel [kh,kw,F,4F], bias [4F])] in Keras layouts;
+        dense_w [inputs, classes], dense_b [classes]."""
+        dev = self.device
+        with torch.cuda.device(dev):
+            for i, (k, rk, b) in enumerate(layers):
+                k, rk, b = (L.f32c(torch.as_tensor(t).to(dev)) for t in (k, rk, b))
+                L.check(L.lib().ivf_tfclstm_load_layer(self._h, i, L.ptr(k), L.ptr(rk), L.ptr(b), L.stream()))
+                torch.cuda.current_stream().synchronize()
+            dw, db = L.f32c(torch.as_tensor(dense_w).to(dev)), L.f32c(torch.as_tensor(dense_b).to(dev))
+            if tuple(dw.shape) != (self.fc_inputs, self.K):
+                raise L.IvfError(f"dense kernel must be [{self.fc_inputs},{self.K}], got {tuple(dw.shape)}")
+            L.check(L.lib().ivf_tfclstm_load_head(self._h, L.ptr(dw), L.ptr(db), L.stream()))
+            torch.cuda.current_stream().synchronize()
+
+    _clip = I3DEngine._clip
+    _targets = I3DEngine._targets
+
+    def forward(self, x, want_logits=False):
+        x = self._clip(x)
+        b = x.shape[0]
+        probs = torch.empty(b, self.K, device=self.device)
+        logits = torch.empty(b, self.K, device=self.device) if want_logits else None
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_tfclstm_forward(self._h, L.ptr(x), b, L.ptr(logits), L.ptr(probs), L.stream()))
+        return (probs, logits) if want_logits else probs
+
+    def backward(self, b, target):
+        C, T, H, W = self.clip_shape
+        tgt = self._targets(target, b)
+        score = torch.empty(b, device=self.device)
+        dx = torch.empty(b, C, T, H, W, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_tfclstm_backward(self._h, b, L.ptr(tgt), L.ptr(score), L.ptr(dx), L.stream()))
+        return score, dx
+
+    def perturbed_forward(self, x, mask):
+        x = self._clip(x)
+        b = x.shape[0]
+        mask = L.f32c(mask.to(self.device))
+        probs = torch.empty(b, self.K, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_tfclstm_perturbed_forward(self._h, L.ptr(x), b, L.ptr(mask), L.ptr(probs), L.stream()))
+        return probs
+
+    def search(self, x, target, raw_mask, lam1, lam2, N, lr=0.2, betas=(0.9, 0.999), eps=1e-8, state=None):
+        x = self._clip(x)
+        b, T = x.shape[0], self.clip_shape[1]
+        tgt = self._targets(target, b)
+        if raw_mask.dtype != torch.float32 or not raw_mask.is_contiguous() or tuple(raw_mask.shape) != (b, T):
+            raise L.IvfError("raw_mask must be a contiguous float32 [b,T] tensor")
+        if state is None:
+            state = (torch.zeros_like(raw_mask), torch.zeros_like(raw_mask), 0)
+        m, v, done = state
+        traj = torch.empty(N, b, 4, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_tfclstm_search(self._h, L.ptr(x), b, L.ptr(tgt), L.ptr(raw_mask), L.ptr(m), L.ptr(v), lam1, lam2,
+                                               lr, betas[0], betas[1], eps, int(N), done + 1, L.ptr(traj), L.stream()))
+        return traj, (m, v, done + int(N))
+
+    def gradcam(self, x, target, mask=None, normalization_mode="frame", out_hw=None):
+        """mask/gradcam.py: per-frame maps [b,T,H,W]; normalization_mode 'frame' | 'sequence' (FLAGS.normalization_mode)."""
+        x = self._clip(x)
+        b = x.shape[0]
+        C, T, H, W = self.clip_shape
+        oh, ow = out_hw if out_hw is not None else (H, W)
+        if normalization_mode not in ("frame", "sequence"):
+            raise L.IvfError("Error. Need to provide normalization mode.")           # gradcam.py:97
+        tgt = self._targets(target, b)
+        m = L.f32c(mask.to(self.device)) if mask is not None else None
+        cam = torch.empty(b, T, oh, ow, device=self.device)
+        probs = torch.empty(b, self.K, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ivf_tfclstm_gradcam(self._h, L.ptr(x), b, L.ptr(m), L.ptr(tgt), 1 if normalization_mode == "frame" else 0,
+                                                oh, ow, L.ptr(cam), L.ptr(probs), L.stream()))
+        return cam, probs

@@ -49,6 +49,11 @@ class I3DConfig(Structure):
         "pool5a_stride_t", "head_kt", "head_kh", "head_kw", "softmax", "math")]
 
 
+class TFCLSTMConfig(Structure):
+    _fields_ = [(n, c_int) for n in ("B", "C", "T", "H", "W", "layers")] + [("units", c_int * 8)] + \
+        [(n, c_int) for n in ("kh", "kw", "stride", "padding", "recurrent_hard_sigmoid", "only_last", "num_classes")]
+
+
 class CLSTMConfig(Structure):
     _fields_ = [(n, c_int) for n in (
         "B", "C", "T", "H", "W", "hidden", "layers", "kernel", "stride", "num_classes",
@@ -146,6 +151,21 @@ _SIGS_OPT = {
     "ivf_clstm_backward": (c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "ivf_clstm_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     "ivf_clstm_perturbed_forward": (c_int, [_P, _P, _I, _P, _I, _P, _P]),
+    # csrc/tf_clstm.hip (documented extension)
+    "ivf_tfclstm_create": (c_int, [POINTER(TFCLSTMConfig), POINTER(c_void_p)]),
+    "ivf_tfclstm_destroy": (None, [_P]),
+    "ivf_tfclstm_weights_bytes": (c_size_t, [_P]),
+    "ivf_tfclstm_workspace_bytes": (c_size_t, [_P]),
+    "ivf_tfclstm_bind": (c_int, [_P, _P, _P]),
+    "ivf_tfclstm_layer_dims": (c_int, [_P, _I] + [POINTER(c_int)] * 5),
+    "ivf_tfclstm_fc_inputs": (c_int, [_P]),
+    "ivf_tfclstm_load_layer": (c_int, [_P, _I, _P, _P, _P, _P]),
+    "ivf_tfclstm_load_head": (c_int, [_P, _P, _P, _P]),
+    "ivf_tfclstm_forward": (c_int, [_P, _P, _I, _P, _P, _P]),
+    "ivf_tfclstm_backward": (c_int, [_P, _I, _P, _P, _P, _P]),
+    "ivf_tfclstm_perturbed_forward": (c_int, [_P, _P, _I, _P, _P, _P]),
+    "ivf_tfclstm_search": (c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "ivf_tfclstm_gradcam": (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
 _lib = None
