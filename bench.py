@@ -449,7 +449,7 @@ def main():
                                          f"I3D mask search + Grad-CAM on 32-frame clips [{sb},3,32,224,224] per step, "
                                          f"stride_mod_layers='none' (BASELINE configs[4]"
                                          f"{'; bf16 activation / gradient storage, fp32 accumulate' if m == 'bf16act' else ''})")
-            for key, m, sb, ss in (("bf16x3", "bf16x3", B, 2), ("fp32_mfma", "fp32", min(16, B), 1)):
+            for key, m, sb, ss in (("bf16x3", "bf16x3", B, 2), ("fp32_mfma", "fp32", min(16, B), 3)):
                 if m != args.math:
                     sec[key] = i3d_block(m, T, sb, ss, 1, f"same search, [{sb},3,{T},224,224] per step, {MODES[m][3]}")
             sec["convlstm"] = convlstm_block(torch, dev)
