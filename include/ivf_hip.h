@@ -312,8 +312,8 @@ typedef struct ivf_i3d ivf_i3d_t;
 int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out);
 /* Run the HBM-bound branch of every Inception module (the 3x3x3 pool and b3b, both ways) on a side
  * stream beside the 3x3x3 convs of the other branches (fork at module entry, join before the next consumer, with
- * events inside every forward / backward call; results are bit-identical).  Off by default (IVF_OVERLAP=1 in the environment of ivf_i3d_create turns it
- * on): +0.7 % measured, see DESIGN.md. */
+ * events inside every forward / backward call; results are bit-identical).  On by default (IVF_OVERLAP=0 in the
+ * environment of ivf_i3d_create turns it off): +1.2 % measured, see DESIGN.md. */
 int ivf_i3d_set_overlap(ivf_i3d_t* net, int on);
 void ivf_i3d_destroy(ivf_i3d_t* net);
 size_t ivf_i3d_weights_bytes(const ivf_i3d_t* net);

@@ -101,11 +101,12 @@ struct ivf_i3d {
   // side stream + fork/join events (created on first use: the plan itself is built without a GPU)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // Off by default: measured +0.7 % clips/s at B = 64.  The branch it hides is HBM-bound and needs about half the
-  // CUs to hold its bandwidth (~24 GB/s per CU), while a 3x3x3 conv workgroup needs a CU to itself (all of its LDS
-  // and registers), so the two mostly trade CUs instead of sharing them (b1b of Mixed_3b: 706 -> 1005 us while
-  // 600 us of side work ran beside it).
-  bool overlap = false;
+  // On by default (IVF_OVERLAP=0 / ivf_i3d_set_overlap(net, 0) turn it off): +1.2 % clips/s at B = 32 in the 6-pass
+  // mode once the fork sits at module entry (round 2 forked at the first side op, behind b1b / b2b: +0.7 %, backward
+  // only).  The branch it hides is HBM-bound and needs about half the CUs to hold its bandwidth (~24 GB/s per CU), while
+  // a 3x3x3 conv workgroup needs a CU to itself (all of its LDS and registers), so the two mostly trade CUs instead of
+  // sharing them.  Results are bit-identical either way (test_side_stream_overlap_is_bit_identical).
+  bool overlap = true;
 
   // (typed float* for the C-ABI's sake: in an IVF_MATH_BF16ACT plan every buffer but the clip holds bf16 elements)
   float* act(int i) const { return (float*)(ws + bufs[i].act_off); }
@@ -667,7 +668,7 @@ extern "C" int ivf_i3d_create(const ivf_i3d_config* cfg, ivf_i3d_t** out) {
   IVF_CHECK_ARG(cfg->math >= IVF_MATH_FP32 && cfg->math <= IVF_MATH_BF16ACT, "i3d_create: unknown math mode");
   ivf_i3d* n = new ivf_i3d();
   n->cfg = *cfg;
-  n->overlap = getenv("IVF_OVERLAP") != nullptr && getenv("IVF_OVERLAP")[0] == '1';
+  n->overlap = !(getenv("IVF_OVERLAP") != nullptr && getenv("IVF_OVERLAP")[0] == '0');   // on unless IVF_OVERLAP=0
   int rc = build_plan(n);
   if (rc != IVF_OK) {
     delete n;

@@ -300,7 +300,7 @@ def test_side_stream_overlap_is_bit_identical(s16):
         probs = s16.forward(x).clone()
         score, dx = s16.backward(2, target=tgt)
         out.append((probs, score.clone(), dx.clone()))
-    s16.set_overlap(False)
+    s16.set_overlap(True)      # (the default)
     for k in (1, 2):
         for a, b in zip(out[0], out[k]):
             assert torch.equal(a, b)

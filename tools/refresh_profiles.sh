@@ -24,7 +24,10 @@ python tools/pmc_mfma.py $O/pm $O/${TAG}_pmc_mfma_util.json > $O/${TAG}_pmc_mfma
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$R/$O/pw" -o p -- python3 bench.py --steps 1 --warmup 0 --iters 6 $B > $O/pw.log 2>&1
 python tools/pmc_waves.py $O/pw $O/${TAG}_pmc_wave_states.json > $O/${TAG}_pmc_wave_states.txt; rm -rf $O/pw
 echo "pmc passes done"
+# (per-layer views map kernels to layers by launch order: the side stream is switched off for this pass only)
+export IVF_OVERLAP=0
 rocprofv3 --kernel-trace -d "$R/$O/ktrace" -o k --output-format csv -- python3 bench.py --steps 1 --warmup 0 --iters 12 $B > $O/ktrace.log 2>&1
+unset IVF_OVERLAP
 python tools/iter_breakdown.py $O/ktrace/k_kernel_trace.csv > $O/${TAG}_iteration_breakdown.txt
 python tools/trace_convs.py $O/ktrace/k_kernel_trace.csv $BATCH 40 $MATH > $O/${TAG}_per_layer_iteration_B${BATCH}.txt 2>&1
 rm -rf $O/ktrace
