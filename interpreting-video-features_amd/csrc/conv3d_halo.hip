@@ -1,6 +1,5 @@
 // LDS-halo convolution (conv3d_halo_impl.h): the AM_X3 instantiations (fp32 activations split hi/lo, 3 MFMA passes)
 // and the mode-independent host side: applicability, variant dispatch by arithmetic mode, built-in variant choice.
-#define IVF_HALO_STAMPS_OWNER   // the stamps build reads the counters of THIS translation unit (AM_X3)
 #include "conv3d_halo_impl.h"
 
 namespace ivf {

@@ -448,9 +448,16 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       constexpr int u = decltype(U)::value;
       const int tap = tap0 + u;   // step index within the chunk (the last round may run past nsteps: no MFMAs then)
       load_b(u, tap + PF, c0);
+      IVF_STAMP(st_t0);
       if (tap < nsteps) mma_tap(tap, tap & 1, nks);
+      IVF_STAMP(st_t1);
       store_b((u + 1) % PF, (tap + 1) & 1);
+#ifndef IVF_EXP_NOBAR
       __syncthreads();
+#endif
+      IVF_STAMP(st_t2);
+      IVF_STAMP_ADD(6, st_t1, st_t0);   // issuing the step's fragment reads and MFMAs
+      IVF_STAMP_ADD(7, st_t2, st_t1);   // weight tile to LDS + the barrier
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
     if constexpr (DMA) {
@@ -559,7 +566,8 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #if defined(IVF_HALO_STAMPS) && defined(IVF_HALO_STAMPS_OWNER)
 }  // namespace ivf
 // slots: 0 total, 1 halo staging (+ first weight tile), 2 tap loops, 3 reduction + epilogue, 4 workgroups,
-// 5 total in 100 MHz s_memrealtime ticks (slot 0 / slot 5 x 100 MHz = the clock the chip held)
+// 5 total in 100 MHz s_memrealtime ticks (slot 0 / slot 5 x 100 MHz = the clock the chip held),
+// 6 / 7 the tap loops split into MFMA issue and weight store + barrier (register-ring variants)
 extern "C" int ivf_debug_halo_stamps(unsigned long long* out8, int reset) {
   IVF_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ivf::g_halo_stamps), 8 * sizeof(unsigned long long)));
   if (reset) {

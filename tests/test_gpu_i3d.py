@@ -514,6 +514,16 @@ def test_i3d_s32_bf16_activations(golden):
     assert e_l < 2e-2 and e_p < 5e-2 and worst_norm < 1e-2          # bf16 storage: 2^-9 per layer
     assert cams['pf'] < 1e-1 and cams['glob'] < 1e-1
     assert e_t < 1e-2                                                 # north_star's trajectory tolerance
+    # the other entry points on bf16 buffers: Grad-CAM on an inner endpoint (ungated target gradient in bf16 storage),
+    # the reverse-operator search, the NCTHW input gradient
+    cam4, _ = eng.gradcam(x, None, per_frame=False, layer='Mixed_4f')
+    ref4, got4 = g.get('none'), cam4[0].cpu().numpy()
+    assert got4.shape == (32, 224, 224) and np.isfinite(got4).all() and 0.0 <= got4.min() and got4.max() <= 1.0 + 1e-6
+    raw2 = torch.from_numpy(g['srch_init'])[None].cuda().contiguous()
+    tr2, _ = eng.search(x, [int(g['s32_target'])], raw2, 0.01, 0.02, 2, mode='reverse')
+    assert torch.isfinite(tr2).all()
+    _, dx = eng.backward(1, target=[int(g['s32_target'])])
+    assert torch.isfinite(dx).all() and float(dx.abs().max()) > 0
 
 
 def _full_search(eng, g, tag, x, lam1, lam2, N, spread):
