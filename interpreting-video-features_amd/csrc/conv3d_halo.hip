@@ -5,6 +5,9 @@
 namespace ivf {
 
 template int conv_halo_launch_variant_am<AM_X3>(ConvKArgs& a, int v, hipStream_t s);
+// the other two modes are instantiated in their own translation units (conv3d_halo_x6.hip, conv3d_halo_bf16.hip)
+extern template int conv_halo_launch_variant_am<AM_X6>(ConvKArgs& a, int v, hipStream_t s);
+extern template int conv_halo_launch_variant_am<AM_BF16>(ConvKArgs& a, int v, hipStream_t s);
 
 int conv_halo_supported(const ConvKArgs& a) {
   if (a.sT != 1 || a.sH != 1 || a.sW != 1) return 0;

@@ -89,7 +89,7 @@ __device__ __forceinline__ void box_pos(int row, int hw_pitch, int* t, int* h, i
 // box_pos): 100 for k = 3 as it is, 121 -> 124 for k = 4, 81 -> 84 for k = 2 (pad rows are
 // never staged nor read).
 template <int TT, int TH, int TW>
-__host__ __device__ inline int halo_plane_rows(int HH, int HW) {
+__host__ __device__ constexpr int halo_plane_rows(int HH, int HW) {
   int ps = HH * HW;
   if (TT == 4 && TW == 8) ps += (4 - ps % 8 + 8) % 8;
   return ps;
@@ -380,8 +380,10 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
     }
   };
 
-  // halo staging, synchronous in batches of 4 loads per thread: 8 float4 groups per halo row (issuing the
-  // next chunk's halo early was measured: nothing gained, 40+ registers lost)
+  // halo staging, synchronous in batches of 4 loads per thread: 8 float4 groups per halo row (fetching the NEXT
+  // chunk's halo into registers under the current chunk's taps was measured twice -- 256-thread tiles in round 2,
+  // the 512-/1024-thread three-plane tiles in round 3 with 16-28 registers to spare: nothing gained either time;
+  // what an ablated staging phase saves (4-12 %) is its memory traffic, not its latency)
   constexpr int NSTG = 4;
   float4 stg[NSTG];
   // (rows are visited in perm8 order, so the item range is padded to whole blocks of 8 rows)
@@ -448,16 +450,9 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
       constexpr int u = decltype(U)::value;
       const int tap = tap0 + u;   // step index within the chunk (the last round may run past nsteps: no MFMAs then)
       load_b(u, tap + PF, c0);
-      IVF_STAMP(st_t0);
       if (tap < nsteps) mma_tap(tap, tap & 1, nks);
-      IVF_STAMP(st_t1);
       store_b((u + 1) % PF, (tap + 1) & 1);
-#ifndef IVF_EXP_NOBAR
       __syncthreads();
-#endif
-      IVF_STAMP(st_t2);
-      IVF_STAMP_ADD(6, st_t1, st_t0);   // issuing the step's fragment reads and MFMAs
-      IVF_STAMP_ADD(7, st_t2, st_t1);   // weight tile to LDS + the barrier
     };
     static_assert(PF == 3, "tap loop is unrolled by hand for a 3-deep ring");
     if constexpr (DMA) {
@@ -566,8 +561,7 @@ __global__ __launch_bounds__((TT * TH * TW / WROWS) * (BN / WCOLS) * KS * 64) vo
 #if defined(IVF_HALO_STAMPS) && defined(IVF_HALO_STAMPS_OWNER)
 }  // namespace ivf
 // slots: 0 total, 1 halo staging (+ first weight tile), 2 tap loops, 3 reduction + epilogue, 4 workgroups,
-// 5 total in 100 MHz s_memrealtime ticks (slot 0 / slot 5 x 100 MHz = the clock the chip held),
-// 6 / 7 the tap loops split into MFMA issue and weight store + barrier (register-ring variants)
+// 5 total in 100 MHz s_memrealtime ticks (slot 0 / slot 5 x 100 MHz = the clock the chip held)
 extern "C" int ivf_debug_halo_stamps(unsigned long long* out8, int reset) {
   IVF_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ivf::g_halo_stamps), 8 * sizeof(unsigned long long)));
   if (reset) {
@@ -640,7 +634,10 @@ static int launch_halo(ConvKArgs& a, int variant_id, hipStream_t s) {
 // wide tiles on 16-channel chunks (what fits beside the THREE activation planes of the 6-pass mode):
 // 60: 4 192 32 x 96 1 (16) 8x8   61: 4 128 32 x 64 1 (16) 8x8   62: 4 192 32 x 96 1 (16) 4x14   63: 4 128 32 x 64 1 (16) 4x14
 // 64: 4 96 32 x 96 1 (16) 4x14   65: 4 64 32 x 64 1 (16) 4x14    66: 4 192 32 x 96 1 (16) 7x8    67: 4 128 32 x 64 1 (16) 7x8
-constexpr int HALO_NUM_VARIANTS = 68;
+// the same wide tiles on 8 waves of 64-row wave tiles (two waves per SIMD with 256 registers each, 9 fragment reads per
+// 12 MFMA groups instead of 12 per 9):
+// 68: 4 192 64 x 96 1 (16) 8x8   69: 4 128 64 x 64 1 (16) 8x8
+constexpr int HALO_NUM_VARIANTS = 70;
 
 // A variant is built for an operand mode only if its LDS footprint fits for the 3x3x3 case (the 6-pass mode holds
 // three activation planes: mostly the 16-channel-chunk variants remain); anything else reports IVF_ERR_UNSUPPORTED.
@@ -734,6 +731,8 @@ int conv_halo_launch_variant_am(ConvKArgs& a, int v, hipStream_t s) {
     case 65: return launch_halo_if<AM, 4, 64, 32, 64, 1, 16, 4, 14>(a, 65, s);
     case 66: return launch_halo_if<AM, 4, 192, 32, 96, 1, 16, 7, 8>(a, 66, s);
     case 67: return launch_halo_if<AM, 4, 128, 32, 64, 1, 16, 7, 8>(a, 67, s);
+    case 68: return launch_halo_if<AM, 4, 192, 64, 96, 1, 16>(a, 68, s);
+    case 69: return launch_halo_if<AM, 4, 128, 64, 64, 1, 16>(a, 69, s);
   }
   set_error("conv3d_halo: unknown variant %d", v);
   return IVF_ERR_BAD_ARG;

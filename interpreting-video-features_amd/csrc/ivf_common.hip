@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ivf
 
 extern "C" const char* ivf_last_error(void) { return ivf::g_err; }
-extern "C" int ivf_version(void) { return 300; }   // (round 3: variant table of 68 LDS-halo tiles, 4 arithmetic modes)
+extern "C" int ivf_version(void) { return 301; }   // (round 3: variant table of 70 LDS-halo tiles, 4 arithmetic modes)
 
 // ---------------------------------------------------------------- launch profiler
 // Optional HIP-event timing of the implicit-GEMM convolution launches, per tile
