@@ -245,7 +245,23 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16_kernel(ConvKArgs a) {
 
   float4 ra[AROWS];
   uint4 rb[NPB][BROWS];
-  const int khw = a.kH * a.kW;
+  // tap decode of k = 4 g (chunk 0) and the per-chunk step BK in the same mixed radix (Cin, kW, kH, kT)
+  int d_ci, d_kw, d_kh, d_kt, s_ci, s_kw, s_kh, s_kt;
+  {
+    const int khw = a.kH * a.kW;
+    int tap = (4 * g) / a.Cin;
+    d_ci = 4 * g - tap * a.Cin;
+    d_kt = tap / khw;
+    int rem = tap - d_kt * khw;
+    d_kh = rem / a.kW;
+    d_kw = rem - d_kh * a.kW;
+    tap = BK / a.Cin;
+    s_ci = BK - tap * a.Cin;
+    s_kt = tap / khw;
+    rem = tap - s_kt * khw;
+    s_kh = rem / a.kW;
+    s_kw = rem - s_kh * a.kW;
+  }
 
   auto load_chunk = [&](int k0) {
     if constexpr (PW) {
@@ -255,27 +271,30 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16_kernel(ConvKArgs a) {
       for (int j = 0; j < AROWS; ++j)
         ra[j] = second ? load_act4<AM>(a.in2, a_o2[j] + kk) : load_act4<AM>(a.in, a_o1[j] + kk);
     } else {
-      int kk = k0 + 4 * g;
-      bool kvalid = kk < a.K;
-      int tap = kvalid ? kk / a.Cin : 0;
-      int ci = kk - tap * a.Cin;
-      int kt = tap / khw;
-      int rem = tap - kt * khw;
-      int kh = rem / a.kW;
-      int kw = rem - kh * a.kW;
+      // this thread's k = k0 + 4 g as (tap (kt, kh, kw), channel): kept as running state, advanced by one chunk per
+      // call -- chunks are visited in order -- with carries instead of three integer divisions per chunk (on the
+      // 4-channel stem, 8 taps per chunk, the decode was a third of the vector instructions of a VALU-bound kernel)
+      const bool kvalid = d_kt < a.kT;
 #pragma unroll
       for (int j = 0; j < AROWS; ++j) {
-        int ti = a_t0[j] + kt, hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+        int ti = a_t0[j] + d_kt, hi = a_h0[j] + d_kh, wi = a_w0[j] + d_kw;
         bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
                   (unsigned)wi < (unsigned)a.Wi;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
           size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
-          v = (a.in2 && kk >= a.K0) ? load_act4<AM>(a.in2, pos * a.in2_ld + a.in2_coff + (kk - a.K0))
-                                    : load_act4<AM>(a.in, pos * a.in_ld + a.in_coff + ci);
+          v = load_act4<AM>(a.in, pos * a.in_ld + a.in_coff + d_ci);
         }
         ra[j] = v;
       }
+      d_ci += s_ci;
+      int cw = s_kw, ch = s_kh;
+      if (d_ci >= a.Cin) { d_ci -= a.Cin; ++cw; }
+      d_kw += cw;
+      if (d_kw >= a.kW) { d_kw -= a.kW; ++ch; }
+      d_kh += ch;
+      if (d_kh >= a.kH) { d_kh -= a.kH; ++d_kt; }
+      d_kt += s_kt;
     }
     int kb = k0 + 8 * g2;
 #pragma unroll
@@ -503,6 +522,10 @@ static int launch_variant(ConvKArgs& a, int math, hipStream_t s) {
   // a plain GEMM over the pixels: no taps, no strides, no padding
   const bool pw = a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 && a.pW == 0 &&
                   a.To == a.Ti && a.Ho == a.Hi && a.Wo == a.Wi && a.K >= 4 && a.K % 4 == 0 && !a.d2s;
+  if (a.in2 && !pw && math != IVF_MATH_FP32) {
+    set_error("conv3d: a second input needs the plain-GEMM form (1x1x1, stride 1, no padding, K a multiple of 4)");
+    return IVF_ERR_UNSUPPORTED;
+  }
   if (math != IVF_MATH_FP32)
     prof_name(cls, "conv3d_igemm_bf16_kernel<%d,%d,%d,%d,%d,%s>", math == IVF_MATH_BF16X6 ? AM_X6 : (math == IVF_MATH_BF16ACT ? AM_BF16 : AM_X3),
               BM, BN, WM, WN, pw ? "true" : "false");

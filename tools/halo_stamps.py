@@ -26,6 +26,7 @@ def run(name, cin, cout, k, thw, variants, bwd_d2s=False):
         L.check(lib.ivf_conv3d_pack_bwd(L.ptr(w), None, L.ptr(wb), 64, 3, 4, 7, 7, 7, 2, 2, 2, 2, 2, 2, mm,
                                         ctypes.byref(geom), L.stream()))
         x = torch.randn(B, 8, 112, 112, 64, device=dev)
+        if os.environ.get('IVF_STAMPS_ZERO'): x.zero_()
         y = torch.empty(B, 16, 224, 224, 4, device=dev)
         d = L.ConvDesc()
         d.B, d.Ti, d.Hi, d.Wi = B, 8, 112, 112
@@ -44,6 +45,7 @@ def run(name, cin, cout, k, thw, variants, bwd_d2s=False):
         wf = torch.empty(lib.ivf_conv3d_pack_fwd_elems(cout, cin, k, k, k, mm), device=dev)
         L.check(lib.ivf_conv3d_pack_fwd(L.ptr(w), L.ptr(wf), cout, cin, cin, k, k, k, mm, L.stream()))
         x = torch.randn(B, *thw, cin, device=dev)
+        if os.environ.get('IVF_STAMPS_ZERO'): x.zero_()   # zero operands: the clock the chip holds when the matrix pipe toggles nothing
         y = torch.empty(B, *thw, cout, device=dev)
         sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
         d = L.ConvDesc()
