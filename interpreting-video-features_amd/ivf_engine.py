@@ -117,10 +117,22 @@ class I3DEngine:
             self.autotune()
 
     # -------------------------------------------------------------- kernel selection
-    def autotune(self, reps=3):
+    def autotune(self, reps=3, sample=None):
         """Time every kernel variant of every convolution at the plan's batch size and keep the
-        fastest per layer and direction.  Results: see get_tuning / set_tuning."""
+        fastest per layer and direction.  Results: see get_tuning / set_tuning.
+
+        The candidates are timed on the plan's own activation / gradient buffers, so these are filled first by one
+        forward + backward of `sample` (a [max_batch,C,T,H,W] clip batch; default: seeded noise in [-1, 1]): on an
+        untouched (all-zero) workspace the matrix pipe toggles nothing, the chip holds a higher clock and the
+        MFMA-dense tiles rank 16-19 % better than they run on data (MI355X_MICROARCH.md, DVFS give-back)."""
         with torch.cuda.device(self.device):
+            if sample is None:
+                g = torch.Generator(device="cpu").manual_seed(0)
+                one = torch.rand((1,) + tuple(self.clip_shape), generator=g) * 2.0 - 1.0
+                sample = one.to(self.device).expand(self.max_batch, *self.clip_shape).contiguous()
+            probs = self.forward(sample)
+            self.backward(sample.shape[0], target=self.argmax(probs), want_dx=False)
+            del sample, probs
             L.check(L.lib().ivf_i3d_autotune(self._h, self.max_batch, int(reps), L.stream()))
             torch.cuda.current_stream().synchronize()
         self._tuned = True
