@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16_kernel(ConvKArgs a) {
       a_h0[j] = ho * a.sH - a.pH;
       a_w0[j] = wo * a.sW - a.pW;
       a_base[j] = b * a.Ti;
-      a_o1[j] = a_o2[j] = 0;
+      // element offset of the window origin (may lie before the tensor: wraps, and is only used added to an in-range tap)
+      a_o1[j] = (size_t)(((long long)((a_base[j] + a_t0[j]) * a.Hi + a_h0[j]) * a.Wi + a_w0[j]) * a.in_ld + a.in_coff);
+      a_o2[j] = 0;
     } else {
       a_t0[j] = -100000; a_h0[j] = 0; a_w0[j] = 0; a_base[j] = 0;
       a_o1[j] = a_o2[j] = 0;
@@ -275,16 +277,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16_kernel(ConvKArgs a) {
       // call -- chunks are visited in order -- with carries instead of three integer divisions per chunk (on the
       // 4-channel stem, 8 taps per chunk, the decode was a third of the vector instructions of a VALU-bound kernel)
       const bool kvalid = d_kt < a.kT;
+      const size_t tapoff = (size_t)((long long)((d_kt * a.Hi + d_kh) * a.Wi + d_kw) * a.in_ld + d_ci);   // same for every row
 #pragma unroll
       for (int j = 0; j < AROWS; ++j) {
         int ti = a_t0[j] + d_kt, hi = a_h0[j] + d_kh, wi = a_w0[j] + d_kw;
         bool ok = kvalid && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
                   (unsigned)wi < (unsigned)a.Wi;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          size_t pos = (size_t)((a_base[j] + ti) * a.Hi + hi) * a.Wi + wi;
-          v = load_act4<AM>(a.in, pos * a.in_ld + a.in_coff + d_ci);
-        }
+        if (ok) v = load_act4<AM>(a.in, a_o1[j] + tapoff);
         ra[j] = v;
       }
       d_ci += s_ci;
