@@ -104,6 +104,19 @@ int ivf_search_step(float* raw_mask, const float* sig, const float* dscore_dsig,
 
 int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream);
 
+/* Integer frame-importance ranking of finished masks (the drivers rank frames by mask value,
+ * FindMasksComparison_I3D_smth.py:216-230): order[b][r] = frame with the r-th largest value of mask[b][:], ties by
+ * frame index, NaN last -- torch.argsort(-mask, stable=True).  mask [B,T] fp32, order [B,T] int32. */
+int ivf_rank_frames(const float* mask, int B, int T, int* order, ivf_stream_t stream);
+
+/* init_mask(mode='central') selection for B clips (mask.py:134-154): orig[b] / full[b] = target score of the clip /
+ * of its fully frozen version, central[b][i] = score under candidate i+1 (ones with i+1 zeros at each end), n
+ * candidates.  ratio[b][i] = (orig - central) / (orig - full) (optional output); chosen_i[b] (optional, 1-based) = first
+ * candidate whose ratio < threshold, else n (NaN compares false, as in the reference); raw_mask[b][t] = -5 on the
+ * chosen candidate's zeros, +5 on its ones. */
+int ivf_init_central_select(const float* orig, const float* full, const float* central, int B, int n, int T,
+                            float threshold, float* raw_mask, int* chosen_i, float* ratio, ivf_stream_t stream);
+
 /* Clip ingest: the arithmetic of ImLoader.__getitem__ /
  * KTHImLoader.__getitem__ after the JPEG decode (data_loader_jpg.py:29-37,
  * data_loader_kth.py:25-44): uint8 frames [B][T][H][W][C] -> float32 (exact), permuted to

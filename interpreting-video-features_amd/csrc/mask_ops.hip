@@ -733,6 +733,63 @@ extern "C" int ivf_clip_ingest_u8(const unsigned char* frames, float* out, int B
   return IVF_OK;
 }
 
+// Frame-importance ranking: order[b][r] = the frame with the r-th largest mask value, ties by frame index (a stable
+// descending sort; NaN values last, in frame order -- what torch.argsort(-mask, stable=True) returns).  One thread
+// per frame counts the frames that come before it.
+__global__ void rank_desc_kernel(const float* __restrict__ mask, int* __restrict__ order, int T) {
+  const float* m = mask + (size_t)blockIdx.x * T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float v = m[t];
+    const bool vnan = v != v;
+    int r = 0;
+    for (int s = 0; s < T; ++s) {
+      const float u = m[s];
+      const bool unan = u != u;
+      const bool before = vnan ? (!unan || s < t) : (!unan && (u > v || (u == v && s < t)));
+      r += before ? 1 : 0;
+    }
+    order[(size_t)blockIdx.x * T + r] = t;
+  }
+}
+
+extern "C" int ivf_rank_frames(const float* mask, int B, int T, int* order, ivf_stream_t stream) {
+  IVF_CHECK_ARG(mask && order && B > 0 && T > 0, "rank_frames: bad args");
+  hipLaunchKernelGGL(rank_desc_kernel, dim3(B), dim3(T < 256 ? ((T + 63) / 64) * 64 : 256), 0, (hipStream_t)stream, mask,
+                     order, T);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
+// init_mask('central') selection (mask.py:134-154) for b clips: candidate i (1-based) = ones with i zeros at each
+// end; ratio_i = (orig - central_i) / (orig - full); the first i whose ratio is below the threshold (NaN compares
+// false, as in the reference), else the last candidate; raw mask = -5 on its zeros, +5 on its ones.
+__global__ void central_select_kernel(const float* __restrict__ orig, const float* __restrict__ full,
+                                      const float* __restrict__ central, int B, int n, int T, float threshold,
+                                      float* __restrict__ raw, int* __restrict__ chosen_i, float* __restrict__ ratio) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int pick = n;   // 1-based
+  bool found = false;
+  for (int i = 0; i < n; ++i) {
+    const float r = (orig[b] - central[(size_t)b * n + i]) / (orig[b] - full[b]);
+    if (ratio) ratio[(size_t)b * n + i] = r;
+    if (!found && r < threshold) { pick = i + 1; found = true; }
+  }
+  if (chosen_i) chosen_i[b] = pick;
+  for (int t = 0; t < T; ++t) raw[(size_t)b * T + t] = (t < pick || t >= T - pick) ? -5.f : 5.f;
+}
+
+extern "C" int ivf_init_central_select(const float* orig, const float* full, const float* central, int B, int n, int T,
+                                       float threshold, float* raw_mask, int* chosen_i, float* ratio,
+                                       ivf_stream_t stream) {
+  IVF_CHECK_ARG(orig && full && central && raw_mask, "init_central_select: null pointer");
+  IVF_CHECK_ARG(B > 0 && n > 0 && T >= 2 * n, "init_central_select: need B > 0 and 0 < n <= T / 2 candidates");
+  hipLaunchKernelGGL(central_select_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, orig, full, central, B, n,
+                     T, threshold, raw_mask, chosen_i, ratio);
+  IVF_CHECK_LAUNCH();
+  return IVF_OK;
+}
+
 extern "C" int ivf_sigmoid(const float* x, float* y, int n, ivf_stream_t stream) {
   IVF_CHECK_ARG(x && y && n > 0, "sigmoid: bad args");
   hipLaunchKernelGGL(sigmoid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);

@@ -79,6 +79,8 @@ _SIGS = {
     "ivf_adam_step": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P]),
     "ivf_search_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P]),
     "ivf_sigmoid": (c_int, [_P, _P, _I, _P]),
+    "ivf_rank_frames": (c_int, [_P, _I, _I, _P, _P]),
+    "ivf_init_central_select": (c_int, [_P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P]),
     "ivf_clip_ingest_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ivf_conv3d": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ivf_bn_fold": (c_int, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

@@ -42,13 +42,16 @@ def init_masks_central(engine, x, target, orig_score, threshold=0.9, mask_type="
     cands = central_masks(T, dev)
     cen = torch.stack([engine.perturbed_forward(x, cands[i][None].expand(b, T).contiguous(), mask_type)[idx, tl]
                        for i in range(cands.shape[0])], dim=1)                                # :139-141
-    ratio = (orig_score[:, None] - cen) / (orig_score[:, None] - full[:, None])               # :142
-    below = ratio < threshold                      # NaN compares False, as in the reference (:143)
-    first = torch.where(below.any(dim=1), below.float().argmax(dim=1),
-                        torch.full((b,), cands.shape[0] - 1, device=dev))
-    chosen = cands[first]                                                                     # :147
-    raw = torch.where(chosen == 0, torch.tensor(-5.0, device=dev), torch.tensor(5.0, device=dev))  # :149-154
-    return raw.contiguous(), dict(full=full, central=cen, ratio=ratio, chosen_i=first + 1)
+    n = cands.shape[0]
+    orig = L.f32c(orig_score)
+    full, cen = L.f32c(full), L.f32c(cen)
+    raw = torch.empty(b, T, device=dev)
+    first = torch.empty(b, dtype=torch.int32, device=dev)
+    ratio = torch.empty(b, n, device=dev)
+    with torch.cuda.device(dev):                                                               # :142-154
+        L.check(L.lib().ivf_init_central_select(L.ptr(orig), L.ptr(full), L.ptr(cen), b, n, T, float(threshold),
+                                                L.ptr(raw), L.ptr(first), L.ptr(ratio), L.stream()))
+    return raw, dict(full=full, central=cen, ratio=ratio, chosen_i=first.long())
 
 
 def find_submasks_host(mask_row, thresh=0.1):
@@ -70,8 +73,14 @@ def find_submasks_host(mask_row, thresh=0.1):
 
 
 def frame_ranking(mask):
-    """Integer frame-importance ranking: stable argsort of -mask."""
-    return torch.argsort(-mask, dim=-1, stable=True)
+    """Integer frame-importance ranking: stable argsort of -mask (ivf_rank_frames)."""
+    m = L.f32c(mask.detach())
+    L.require_gpu(m)
+    T = m.shape[-1]
+    order = torch.empty(m.shape, dtype=torch.int32, device=m.device)
+    with torch.cuda.device(m.device):
+        L.check(L.lib().ivf_rank_frames(L.ptr(m), m.numel() // T, T, L.ptr(order), L.stream()))
+    return order.long()
 
 
 class MaskSearch:

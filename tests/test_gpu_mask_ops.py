@@ -153,3 +153,54 @@ def test_regulariser_and_adam(golden):
                                       0.9, 0.999, 1e-8, L.stream()))
         traj.append(p.cpu().numpy().copy())
     assert np.allclose(np.array(traj), g['adam_traj'], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("T", [16, 32, 100])
+def test_rank_frames_is_stable_descending_argsort(T):
+    """ivf_rank_frames == torch.argsort(-mask, stable=True): ties by frame index, NaN last (the integer ranking
+    the drivers report, FindMasksComparison_I3D_smth.py:216-230)."""
+    import ivf_lib as L
+    import ivf_search
+    gen = torch.Generator().manual_seed(T)
+    m = torch.rand(7, T, generator=gen)
+    m[1] = (m[1] * 4).round() / 4            # many ties
+    m[2] = 0.5                               # all equal
+    m[3, ::3] = float('nan')                 # NaN entries (a val == 0 TV gradient poisons the mask, mask.py:97)
+    m[4] = torch.linspace(1, 0, T)           # already sorted
+    m[5] = torch.linspace(0, 1, T)           # reversed
+    mg = m.cuda()
+    order = torch.empty(7, T, dtype=torch.int32, device='cuda')
+    L.check(L.lib().ivf_rank_frames(L.ptr(mg), 7, T, L.ptr(order), L.stream()))
+    ref = torch.argsort(-m, dim=-1, stable=True)
+    assert torch.equal(order.cpu().long(), ref)
+    assert torch.equal(ivf_search.frame_ranking(mg).cpu(), ref)
+
+
+def test_init_central_select_matches_reference_rule():
+    """ivf_init_central_select == mask.py:134-154 restated with torch: first candidate whose score ratio drops below
+    the threshold, else the last one; NaN ratios (orig == full) compare false."""
+    import ivf_lib as L
+    T, n, B = 16, 7, 9
+    gen = torch.Generator().manual_seed(3)
+    orig = torch.rand(B, generator=gen) * 0.5 + 0.5
+    full = torch.rand(B, generator=gen) * 0.3
+    cen = orig[:, None] - (orig - full)[:, None] * torch.sort(torch.rand(B, n, generator=gen), dim=1).values
+    cen[0] = orig[0]                 # ratio 0 everywhere -> below the threshold at i = 1
+    cen[1] = full[1]                 # ratio 1 everywhere -> never below: last candidate
+    full[2] = orig[2]                # 0 / 0 and x / 0: NaN / inf, never below
+    thr = 0.5
+    ratio = (orig[:, None] - cen) / (orig[:, None] - full[:, None])
+    below = ratio < thr
+    first = torch.where(below.any(dim=1), below.float().argmax(dim=1), torch.full((B,), n - 1))
+    t = torch.arange(T)[None]
+    pick = (first + 1)[:, None]
+    raw_ref = torch.where((t < pick) | (t >= T - pick), torch.tensor(-5.0), torch.tensor(5.0))
+    raw = torch.empty(B, T, device='cuda')
+    chosen = torch.empty(B, dtype=torch.int32, device='cuda')
+    rat = torch.empty(B, n, device='cuda')
+    og, fg, cg = orig.cuda(), full.cuda(), cen.cuda().contiguous()      # (kept alive across the launch)
+    L.check(L.lib().ivf_init_central_select(L.ptr(og), L.ptr(fg), L.ptr(cg), B, n, T, thr, L.ptr(raw), L.ptr(chosen),
+                                            L.ptr(rat), L.stream()))
+    assert torch.equal(chosen.cpu().long(), first + 1)
+    assert torch.equal(raw.cpu(), raw_ref)
+    assert torch.allclose(rat.cpu(), ratio, rtol=1e-6, atol=0, equal_nan=True)
