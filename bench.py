@@ -61,6 +61,7 @@ MODES = {
 }
 HEADLINE_MATH = "bf16x6"
 NCLASS = 96   # IVF_PROFILE_CLASSES
+GATHER_CAMS = os.environ.get("IVF_BENCH_GATHER_CAMS") == "1"   # also all-gather the Grad-CAM maps (SURVEY 8e's optional payload)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
 
 
@@ -309,7 +310,7 @@ def timed_i3d(torch, dist, dev, rank, world, math, B, T, iters, steps, warmup, l
 
     def step(i):
         res = searcher.run(batches[i], labels[i])
-        rec = ivf_search.pack_records(clip_ids[i], res, T)
+        rec = ivf_search.pack_records(clip_ids[i], res, T, with_cam=GATHER_CAMS)   # (maps: 3.2 MB per clip, optional)
         return ivf_shard.gather_records(rec, equal_shards=True)    # ONE RCCL all_gather when world > 1
 
     def fence():

@@ -140,18 +140,26 @@ RECORD_FLOAT_FIELDS = ("original_score_guess", "original_score_true", "freeze_sc
 RECORD_FIELDS = RECORD_INT_FIELDS + RECORD_FLOAT_FIELDS
 
 
-def pack_records(clip_ids, res, T):
-    """Fixed-size per-clip record [b, 7+T] int32 for the all-gather: clip id,
-    pred_class, target as integers; the four scores and sigma(mask)[T] as bit-cast float32."""
+def pack_records(clip_ids, res, T, with_cam=False):
+    """Fixed-size per-clip record [b, 7+T (+ cam)] int32 for the all-gather: clip id,
+    pred_class, target as integers; the four scores and sigma(mask)[T] as bit-cast float32.
+    with_cam=True appends the clip's Grad-CAM map res["gradcam"] [T', h, w] (bit-cast float32, row-major) -- the
+    optional payload of SURVEY.md 8e; at [16,224,224] that is 3.2 MB per clip, a few milliseconds of xGMI time per
+    step of 32 clips per GPU against seconds of search.  Every rank must use the same map shape."""
     dev = res["pred_class"].device
     ints = [torch.as_tensor(clip_ids, device=dev).to(torch.int32)]
     ints += [res[k].to(torch.int32) for k in RECORD_INT_FIELDS[1:]]
     flt = torch.stack([res[k].float() for k in RECORD_FLOAT_FIELDS], dim=1)
-    flt = torch.cat([flt, res["time_mask"].float()], dim=1).contiguous()
+    parts = [flt, res["time_mask"].float()]
+    if with_cam:
+        cam = res["gradcam"]
+        parts.append(cam.float().reshape(cam.shape[0], -1))
+    flt = torch.cat(parts, dim=1).contiguous()
     return torch.cat([torch.stack(ints, dim=1), flt.view(torch.int32)], dim=1).contiguous()
 
 
-def unpack_record(row, T):
+def unpack_record(row, T, cam_shape=None):
+    """One gathered row -> dict; cam_shape = (T', h, w) when the rows carry Grad-CAM maps (pack_records(with_cam=True))."""
     row = row.detach().cpu().contiguous()
     ni = len(RECORD_INT_FIELDS)
     d = {k: int(row[i]) for i, k in enumerate(RECORD_INT_FIELDS)}
@@ -160,4 +168,9 @@ def unpack_record(row, T):
         d[k] = float(f[i])
     nf = len(RECORD_FLOAT_FIELDS)
     d["time_mask"] = f[nf:nf + T].numpy().copy()
+    if cam_shape is not None:
+        n = int(np.prod(cam_shape))
+        if f.numel() != nf + T + n:
+            raise L.IvfError(f"record has {f.numel() - nf - T} map values, cam_shape {tuple(cam_shape)} needs {n}")
+        d["gradcam"] = f[nf + T:].numpy().reshape(cam_shape).copy()
     return d
