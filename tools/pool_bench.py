@@ -9,18 +9,22 @@ cases = {'3c.b3a': (64, 8, 28, 28, 480, (3,3,3), (1,1,1)), '2a': (64, 8, 112, 11
          '4f.b3a': (64, 4, 14, 14, 528, (3,3,3), (1,1,1))}
 import ivf_arch as arch
 for name, (B, T, H, W, C, k, s) in cases.items():
-    x = torch.relu(torch.randn(B, T, H, W, C, device='cuda'))
+    BF = os.environ.get("IVF_POOL_BF16") == "1"      # bf16 activation storage (PoolDesc.act_bf16)
+    dt = torch.bfloat16 if BF else torch.float32
+    x = torch.relu(torch.randn(B, T, H, W, C, device='cuda')).to(dt)
     pads = [arch.same_pad(n, kk, ss)[0] for n, kk, ss in zip((T,H,W), k, s)]
     outs = [arch.out_size(n, kk, ss) for n, kk, ss in zip((T,H,W), k, s)]
-    y = torch.empty(B, *outs, C, device='cuda'); idx = torch.empty(B, *outs, C, dtype=torch.uint8, device='cuda')
+    y = torch.empty(B, *outs, C, device='cuda', dtype=dt); idx = torch.empty(B, *outs, C, dtype=torch.uint8, device='cuda')
     dy = torch.randn_like(y); dx = torch.empty_like(x)
+    esz = 2 if BF else 4
     d = L.PoolDesc()
     d.B, d.Ti, d.Hi, d.Wi, d.C, d.in_ld, d.in_coff = B, T, H, W, C, C, 0
     d.To, d.Ho, d.Wo, d.out_ld, d.out_coff = *outs, C, 0
     d.kT, d.kH, d.kW = k; d.sT, d.sH, d.sW = s; d.pT, d.pH, d.pW = pads
+    d.act_bf16 = 1 if BF else 0
     def fwd(): L.check(lib.ivf_maxpool3d_fwd(ctypes.byref(d), L.ptr(x), L.ptr(y), L.ptr(idx), L.stream()))
     def bwd(): L.check(lib.ivf_maxpool3d_bwd(ctypes.byref(d), L.ptr(dy), L.ptr(idx), L.ptr(dx), L.ptr(x), 0, L.stream()))
-    for fn, label, bytes_ in ((fwd, 'fwd', x.numel()*4 + y.numel()*5), (bwd, 'bwd', dy.numel()*5 + dx.numel()*8)):
+    for fn, label, bytes_ in ((fwd, 'fwd', x.numel()*esz + y.numel()*(esz+1)), (bwd, 'bwd', dy.numel()*(esz+1) + dx.numel()*2*esz)):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
