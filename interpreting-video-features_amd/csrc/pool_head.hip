@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const T* __restrict
   const int c = slab * G * 4 + 4 * g;
   if (w >= a.Wi || c >= a.C) return;
   const int h0 = ih * S1_TH;
+  // (lane pairs share loads only when both lanes exist and the pair's 16 bytes are aligned: block-uniform)
+  const bool pair_ok = sizeof(T) == 2 && (G & 1) == 0 && (a.C & 7) == 0 && (a.in_ld & 7) == 0 && (a.in_coff & 7) == 0;
   float pv1[S1_TH][4], pv2[S1_TH][4];
   unsigned pi1[S1_TH], pi2[S1_TH];   // 2-D taps (kh*3+kw), one byte per channel
 #pragma unroll
@@ -460,17 +462,82 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const T* __restrict
     if (t < a.Ti) {
       float rv[S1_TH + 2][4];
       unsigned ri[S1_TH + 2];
+      // bf16 storage.  (1) The raw bits of ALL rows are requested before any is converted: with the conversion next
+      // to the load the compiler waited (`s_waitcnt vmcnt(0)`) inside every bounds branch, 42 serial round trips per
+      // plane where the fp32 form has one, and the bf16 pools ran 1.7x SLOWER than the fp32 ones.  (2) An 8-byte load
+      // per lane moves half the bytes per load instruction, so two lanes that hold neighbouring channel groups
+      // (g even / odd: 16 contiguous bytes) share their loads: the even lane fetches both groups of row r, the odd
+      // lane both groups of row r + 1, and they swap halves (two DPP moves).
+      float4 vp[(S1_TH + 3) / 2 * 2][3];
+      if constexpr (sizeof(T) == 2) {
+        const bool odd = (g & 1) != 0;
+        if (pair_ok) {
+          const int cp = c & ~7;   // first channel of the pair
+          uint4 raw[(S1_TH + 3) / 2][3];
+#pragma unroll
+          for (int r2 = 0; r2 < (S1_TH + 3) / 2; ++r2) {
+            const int hi = h0 - 1 + 2 * r2 + (odd ? 1 : 0);   // the row THIS lane fetches
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int wi = w - 1 + j;
+              raw[r2][j] = make_uint4(0u, 0u, 0u, 0u);
+              if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && 2 * r2 + (odd ? 1 : 0) < S1_TH + 2)
+                raw[r2][j] = *reinterpret_cast<const uint4*>(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + cp);
+            }
+          }
+#pragma unroll
+          for (int r2 = 0; r2 < (S1_TH + 3) / 2; ++r2) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const uint4 u = raw[r2][j];
+              // even lane keeps its low half (row 2 r2) and receives the partner's low half (row 2 r2 + 1);
+              // odd lane receives the partner's high half (row 2 r2) and keeps its own high half (row 2 r2 + 1)
+              const unsigned s0 = odd ? u.x : u.z, s1 = odd ? u.y : u.w;
+              const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+              const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xb1, 0xf, 0xf, false);
+              const unsigned a0 = odd ? g0 : u.x, a1 = odd ? g1 : u.y;     // row 2 r2, this lane's 4 channels
+              const unsigned b0 = odd ? u.z : g0, b1 = odd ? u.w : g1;     // row 2 r2 + 1
+              vp[2 * r2][j] = make_float4(__uint_as_float(a0 << 16), __uint_as_float(a0 & 0xffff0000u),
+                                          __uint_as_float(a1 << 16), __uint_as_float(a1 & 0xffff0000u));
+              vp[2 * r2 + 1][j] = make_float4(__uint_as_float(b0 << 16), __uint_as_float(b0 & 0xffff0000u),
+                                              __uint_as_float(b1 << 16), __uint_as_float(b1 & 0xffff0000u));
+            }
+          }
+        } else {
+          uint2 raw[S1_TH + 2][3];
+#pragma unroll
+          for (int r = 0; r < S1_TH + 2; ++r) {
+            const int hi = h0 - 1 + r;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int wi = w - 1 + j;
+              raw[r][j] = make_uint2(0u, 0u);
+              if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+                raw[r][j] = *reinterpret_cast<const uint2*>(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + c);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < S1_TH + 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              vp[r][j] = make_float4(__uint_as_float(raw[r][j].x << 16), __uint_as_float(raw[r][j].x & 0xffff0000u),
+                                     __uint_as_float(raw[r][j].y << 16), __uint_as_float(raw[r][j].y & 0xffff0000u));
+        }
+      }
 #pragma unroll
       for (int r = 0; r < S1_TH + 2; ++r) {
         const int hi = h0 - 1 + r;
         float4 v[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const int wi = w - 1 + j;
-          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-            v[j] = ld4(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld +
-                                                    a.in_coff + c);
+          if constexpr (sizeof(T) == 2) {
+            v[j] = vp[r][j];
+          } else {
+            const int wi = w - 1 + j;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+              v[j] = ld4(x + ((size_t)((b * a.Ti + t) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + c);
+          }
         }
         const float v0[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
         const float v1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
@@ -589,6 +656,27 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* __restrict
     st4(dst, make_float4(o[0], o[1], o[2], o[3]));
   };
   for (int to = 0; to < a.To; ++to) {
+    // bf16 storage: the raw bits of all nine neighbours are requested before any is converted (with the conversion
+    // beside the load the compiler waits inside every bounds branch: nine serial round trips per plane)
+    uint2 raw[3][3];
+    unsigned ui[3][3];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int ho = h - 1 + r;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int wo = w - 1 + j;
+          raw[r][j] = make_uint2(0u, 0u);
+          ui[r][j] = 0xffffffffu;
+          if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+            const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+            raw[r][j] = *reinterpret_cast<const uint2*>(dy + mo * a.out_ld + a.out_coff + c);
+            ui[r][j] = *reinterpret_cast<const unsigned*>(idx + mo * a.C + c);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int ho = h - 1 + r;
@@ -599,7 +687,11 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* __restrict
         const int kw = 2 - j;
         float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned u = 0xffffffffu;   // matches no tap
-        if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+        if constexpr (sizeof(T) == 2) {
+          gq = make_float4(__uint_as_float(raw[r][j].x << 16), __uint_as_float(raw[r][j].x & 0xffff0000u),
+                           __uint_as_float(raw[r][j].y << 16), __uint_as_float(raw[r][j].y & 0xffff0000u));
+          u = ui[r][j];
+        } else if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
           const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
           gq = ld4(dy + mo * a.out_ld + a.out_coff + c);
           u = *reinterpret_cast<const unsigned*>(idx + mo * a.C + c);
