@@ -101,6 +101,88 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
   }
 }
 
+// The same forward with the window known at compile time and 16 bytes per lane (4 fp32 or 8 bf16 channels): every
+// tap's raw bits are requested up front and scanned afterwards -- in the generic kernel each load is consumed inside
+// its bounds branch, i.e. waited for at once, which the fp32 form hides behind occupancy (4.6 TB/s) and the bf16
+// form, with half the bytes per instruction, does not (2.7 TB/s of its own bytes).
+template <class T, int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool_fwd_fixed_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                unsigned char* __restrict__ idx, PoolArgs a, int nbx) {
+  constexpr int NCH = 16 / (int)sizeof(T);
+  const unsigned CG = (unsigned)a.C / NCH;
+  unsigned blk = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const unsigned bx = blk % (unsigned)nbx; blk /= (unsigned)nbx;
+  const unsigned r = bx * blockDim.x + threadIdx.x;
+  if (r >= (unsigned)a.Wo * CG) return;
+  const int wo = (int)(r / CG);
+  const int c = (int)(r - (unsigned)wo * CG) * NCH;
+  const int ho = (int)(blk % (unsigned)a.Ho); blk /= (unsigned)a.Ho;
+  const int to = (int)(blk % (unsigned)a.To);
+  const int b = (int)(blk / (unsigned)a.To);
+  const size_t m = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+  uint4 raw[KT * KH * KW];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int ti = to * a.sT - a.pT + kt;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hi = ho * a.sH - a.pH + kh;
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const int wi = wo * a.sW - a.pW + kw;
+        uint4 u = make_uint4(0u, 0u, 0u, 0u);   // the zero padding takes part in the scan
+        if ((unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+          u = *reinterpret_cast<const uint4*>(x + ((size_t)((b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi) * a.in_ld + a.in_coff + c);
+        raw[(kt * KH + kh) * KW + kw] = u;
+      }
+    }
+  }
+  float best[NCH];
+  unsigned bi[NCH];
+#pragma unroll
+  for (int tap = 0; tap < KT * KH * KW; ++tap) {
+    const unsigned w4[4] = {raw[tap].x, raw[tap].y, raw[tap].z, raw[tap].w};
+    float vv[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      if constexpr (sizeof(T) == 2) vv[q] = __uint_as_float((q & 1) ? (w4[q >> 1] & 0xffff0000u) : (w4[q >> 1] << 16));
+      else vv[q] = __uint_as_float(w4[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      if (tap == 0 || vv[q] > best[q] || vv[q] != vv[q]) {
+        best[q] = vv[q];
+        bi[q] = (unsigned)tap;
+      }
+    }
+  }
+  T* dst = y + m * a.out_ld + a.out_coff + c;
+  st4(dst, make_float4(best[0], best[1], best[2], best[3]));
+  if constexpr (sizeof(T) == 2) st4(dst + 4, make_float4(best[4], best[5], best[6], best[7]));
+  if (idx) {
+    if (a.dead)
+#pragma unroll
+      for (int q = 0; q < NCH; ++q)
+        if (!(best[q] > 0.f)) bi[q] = 255u;
+    unsigned pk[NCH / 4];
+#pragma unroll
+    for (int k = 0; k < NCH / 4; ++k) pk[k] = bi[4 * k] | (bi[4 * k + 1] << 8) | (bi[4 * k + 2] << 16) | (bi[4 * k + 3] << 24);
+    if constexpr (NCH == 8) *reinterpret_cast<uint2*>(idx + m * a.C + c) = make_uint2(pk[0], pk[1]);
+    else *reinterpret_cast<unsigned*>(idx + m * a.C + c) = pk[0];
+  }
+}
+
+template <class T, int KT, int KH, int KW>
+static bool launch_pool_fwd_fixed(const PoolArgs& a, const T* x, T* y, unsigned char* argmax, hipStream_t s) {
+  constexpr int NCH = 16 / (int)sizeof(T);
+  if (a.kT != KT || a.kH != KH || a.kW != KW) return false;
+  if (a.C % NCH || a.in_ld % NCH || a.in_coff % NCH || a.out_ld % NCH || a.out_coff % NCH) return false;
+  const long nbx = cdiv((long)a.Wo * (a.C / NCH), 256), nblk = nbx * a.Ho * a.B * a.To;
+  if (nblk >= 0x7fffffffL) return false;
+  hipLaunchKernelGGL((maxpool_fwd_fixed_kernel<T, KT, KH, KW>), dim3((unsigned)nblk), dim3(256), 0, s, x, y, argmax, a, (int)nbx);
+  return true;
+}
+
 // backward: for every input cell sum dY of the windows whose recorded winner is
 // this cell.  dy has (out_ld, out_coff) geometry, dx has (in_ld, in_coff).
 template <class T>
@@ -249,6 +331,126 @@ static bool launch_pool_bwd_fixed(const PoolArgs& a, const T* dy, const unsigned
   if (a.Hi > 65535 || (long)a.B * a.Ti > 65535) return false;
   hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT, KH, KW, ST, SH, SW>),
                      dim3((unsigned)cdiv((long)a.Wi * (a.C / 4), 256), (unsigned)a.Hi, (unsigned)(a.B * a.Ti)), dim3(256), 0, s,
+                     dy, idx, dx, relu_mask, accumulate, a);
+  return true;
+}
+
+// The same backward with 16 bytes of channels per lane and every candidate's RAW bits requested first (bf16 storage:
+// 8 channels per thread halve the instructions per byte; measured on fp32 the form above is faster, so it keeps it).
+// backward for the strided pools with the window geometry known at compile time: at most
+// ceil(k/s) outputs per dimension cover an input cell (2 x 2 for the 1x3x3 / (1,2,2) pools),
+// so every candidate's (dY, arg-max) load is issued up front, unconditionally predicated --
+// no dependent loops, neighbouring cells' re-reads come from L1.  One thread per input cell
+// and 16 bytes of channels; contributions are added in ascending (to, ho, wo) order like everywhere else.
+template <class T, int KT, int KH, int KW, int ST, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_bwd_fixed16_kernel(const T* __restrict__ dy,
+                                                                const unsigned char* __restrict__ idx,
+                                                                T* __restrict__ dx,
+                                                                const T* __restrict__ relu_mask, int accumulate,
+                                                                PoolArgs a) {
+  constexpr int NT = (KT + ST - 1) / ST, NH = (KH + SH - 1) / SH, NW = (KW + SW - 1) / SW;
+  constexpr int NCH = 16 / (int)sizeof(T);   // 16 bytes per lane: 4 fp32 or 8 bf16 channels
+  // grid (blocks of one image row's (w, channel group) cells, h, clip * frame): the row coordinates come from the
+  // block index on the scalar unit, one 32-bit division per thread is left (a flat 64-bit index cost five 64-bit
+  // divisions per thread: this kernel ran at 2.6 TB/s beside a forward at 4.8 over the same bytes).
+  // (Numbering the workgroups so that each XCD owns a contiguous run of rows -- as the forward does -- was measured in
+  // round 3: 5 % SLOWER here.)
+  const unsigned CG = (unsigned)a.C / NCH;
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (unsigned)a.Wi * CG) return;
+  const int wi = (int)(r / CG);
+  const int c = (int)(r - (unsigned)wi * CG) * NCH;
+  const int hi = blockIdx.y;
+  const int ti = (int)(blockIdx.z % (unsigned)a.Ti);
+  const int b = (int)(blockIdx.z / (unsigned)a.Ti);
+  const size_t m = ((size_t)(b * a.Ti + ti) * a.Hi + hi) * a.Wi + wi;
+  const int nt = ti + a.pT, nh = hi + a.pH, nw = wi + a.pW;
+  // raw bits of every candidate first (dY: 16 bytes, arg-max: NCH bytes), compared and converted afterwards: a value
+  // consumed inside its bounds branch is waited for at once
+  uint4 g[NT][NH][NW];
+  unsigned u[NT][NH][NW][NCH / 4];
+  unsigned tp[NT][NH][NW];
+  // candidate j along a dim: output o = n/s - (N-1-j) (ascending in j), tap k = n - o*s
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int to = nt / ST - (NT - 1 - jt), kt = nt - to * ST;
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) {
+      const int ho = nh / SH - (NH - 1 - jh), kh = nh - ho * SH;
+#pragma unroll
+      for (int jw = 0; jw < NW; ++jw) {
+        const int wo = nw / SW - (NW - 1 - jw), kw = nw - wo * SW;
+        const bool ok = to >= 0 && to < a.To && kt < KT && ho >= 0 && ho < a.Ho && kh < KH && wo >= 0 &&
+                        wo < a.Wo && kw < KW;
+        g[jt][jh][jw] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < NCH / 4; ++k) u[jt][jh][jw][k] = 0xffffffffu;
+        tp[jt][jh][jw] = ok ? (unsigned)((kt * KH + kh) * KW + kw) * 0x01010101u : 0u;   // (0xff never equals a tap)
+        if (ok) {
+          const size_t mo = ((size_t)(b * a.To + to) * a.Ho + ho) * a.Wo + wo;
+          g[jt][jh][jw] = *reinterpret_cast<const uint4*>(dy + mo * a.out_ld + a.out_coff + c);
+          if constexpr (NCH == 8) {
+            const uint2 t2 = *reinterpret_cast<const uint2*>(idx + mo * a.C + c);
+            u[jt][jh][jw][0] = t2.x;
+            u[jt][jh][jw][1] = t2.y;
+          } else {
+            // (fp32: XOR-ed at once, i.e. waited for inside the branch -- measured 9 % FASTER than the all-up-front
+            // form on this bandwidth-bound variant: 827 vs 903 us on MaxPool3d_2a at B=64)
+            u[jt][jh][jw][0] = *reinterpret_cast<const unsigned*>(idx + mo * a.C + c) ^ tp[jt][jh][jw];
+          }
+        }
+      }
+    }
+  }
+  float acc[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) acc[q] = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh)
+#pragma unroll
+      for (int jw = 0; jw < NW; ++jw) {
+        const unsigned w4[4] = {g[jt][jh][jw].x, g[jt][jh][jw].y, g[jt][jh][jw].z, g[jt][jh][jw].w};
+        unsigned xr[NCH / 4];   // recorded taps XOR own tap: zero byte = this cell won that window
+#pragma unroll
+        for (int k = 0; k < NCH / 4; ++k) xr[k] = NCH == 4 ? u[jt][jh][jw][k] : (u[jt][jh][jw][k] ^ tp[jt][jh][jw]);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+          float v;
+          if constexpr (sizeof(T) == 2) v = __uint_as_float((q & 1) ? (w4[q >> 1] & 0xffff0000u) : (w4[q >> 1] << 16));
+          else v = __uint_as_float(w4[q]);
+          if ((xr[q >> 2] & (0xffu << (8 * (q & 3)))) == 0u) acc[q] += v;
+        }
+      }
+  T* dst = dx + m * a.in_ld + a.in_coff + c;
+#pragma unroll
+  for (int k = 0; k < NCH / 4; ++k) {
+    float* o = acc + 4 * k;
+    if (accumulate) {
+      float4 old = ld4(dst + 4 * k);
+      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+    }
+    if (relu_mask) {
+      float4 kk = ld4(relu_mask + m * a.in_ld + a.in_coff + c + 4 * k);
+      if (!(kk.x > 0.f)) o[0] = 0.f;
+      if (!(kk.y > 0.f)) o[1] = 0.f;
+      if (!(kk.z > 0.f)) o[2] = 0.f;
+      if (!(kk.w > 0.f)) o[3] = 0.f;
+    }
+    st4(dst + 4 * k, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+template <class T, int KT, int KH, int KW, int ST, int SH, int SW>
+static bool launch_pool_bwd_fixed16(const PoolArgs& a, const T* dy, const unsigned char* idx, T* dx,
+                                  const T* relu_mask, int accumulate, hipStream_t s) {
+  constexpr int NCH = 16 / (int)sizeof(T);
+  if (a.kT != KT || a.kH != KH || a.kW != KW || a.sT != ST || a.sH != SH || a.sW != SW) return false;
+  if (a.Hi > 65535 || (long)a.B * a.Ti > 65535) return false;
+  if (a.C % NCH || a.in_ld % NCH || a.in_coff % NCH || a.out_ld % NCH || a.out_coff % NCH) return false;
+  hipLaunchKernelGGL((maxpool_bwd_fixed16_kernel<T, KT, KH, KW, ST, SH, SW>),
+                     dim3((unsigned)cdiv((long)a.Wi * (a.C / NCH), 256), (unsigned)a.Hi, (unsigned)(a.B * a.Ti)), dim3(256), 0, s,
                      dy, idx, dx, relu_mask, accumulate, a);
   return true;
 }
@@ -1051,6 +1253,15 @@ static int pool_fwd_impl(const PoolArgs& a, const T* x, T* y, unsigned char* arg
     IVF_CHECK_LAUNCH();
     return IVF_OK;
   }
+  // the strided pools of the I3D variants with their windows known at compile time
+  static const bool no_fixed = getenv("IVF_POOL_NO_FIXED") != nullptr;
+  if (!direct && !no_fixed && (a.sT > 1 || a.sH > 1 || a.sW > 1)) {
+    if (launch_pool_fwd_fixed<T, 1, 3, 3>(a, x, y, argmax, stream) || launch_pool_fwd_fixed<T, 3, 3, 3>(a, x, y, argmax, stream) ||
+        launch_pool_fwd_fixed<T, 2, 2, 2>(a, x, y, argmax, stream)) {
+      IVF_CHECK_LAUNCH();
+      return IVF_OK;
+    }
+  }
   const long nbx = cdiv((long)a.Wo * (a.C / 4), 256), nblk = nbx * a.Ho * a.B * a.To;
   IVF_CHECK_ARG(nblk < 0x7fffffffL, "maxpool_fwd: more than 2^31 workgroups");
   hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, stream, x, y, argmax, a, (int)nbx);
@@ -1086,6 +1297,16 @@ static int pool_bwd_impl(const PoolArgs& a, const T* dy, const unsigned char* ar
   // the strided pools of the I3D variants (I3D_doubled.py:272-300; temporal strides 1 or 2)
   static const bool no_fixed = getenv("IVF_POOL_NO_FIXED") != nullptr;
   if (!direct && !no_fixed && (size_t)a.B * a.Ti * a.Hi * a.Wi * (a.C / 4) / 256 < 0x7fffffffu) {
+    if constexpr (sizeof(T) == 2) {   // 16-byte lanes, raw loads first
+      if (launch_pool_bwd_fixed16<T, 1, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+          launch_pool_bwd_fixed16<T, 3, 3, 3, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+          launch_pool_bwd_fixed16<T, 3, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+          launch_pool_bwd_fixed16<T, 2, 2, 2, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
+          launch_pool_bwd_fixed16<T, 2, 2, 2, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs)) {
+        IVF_CHECK_LAUNCH();
+        return IVF_OK;
+      }
+    }
     if (launch_pool_bwd_fixed<T, 1, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
         launch_pool_bwd_fixed<T, 3, 3, 3, 2, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
         launch_pool_bwd_fixed<T, 3, 3, 3, 1, 2, 2>(a, dy, argmax, dx, relu_mask, accumulate, hs) ||
