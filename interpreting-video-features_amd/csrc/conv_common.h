@@ -300,13 +300,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           old4[g] = (a.accumulate && ok) ? ep_ld4<OB>(obase, ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
           gate4[g] = (a.mask && ok) ? ep_ld4<OB>(a.mask, (size_t)m * a.mask_ld + a.mask_coff + nq)
                                     : make_float4(1.f, 1.f, 1.f, 1.f);
-          unsigned nib = 15u;
-          if (a.gbi && ok) {
-            const int c = a.gbi_coff + nq;
-            nib = ((unsigned)a.gbi[(size_t)m * a.gbi_ld + (c >> 3)] >> (c & 4)) & 15u;
-          }
-          gnib[g] = nib;
+          // (the raw gate byte; its nibble is taken after all loads of the row tile are out: a value consumed inside
+          // its bounds branch is waited for at once)
+          unsigned gb = 0xffu;
+          if (a.gbi && ok) gb = a.gbi[(size_t)m * a.gbi_ld + ((a.gbi_coff + nq) >> 3)];
+          gnib[g] = gb;
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gnib[g] = (gnib[g] >> ((a.gbi_coff + nq) & 4)) & 15u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v[4];
