@@ -182,6 +182,21 @@ template <bool OB> __device__ __forceinline__ float4 ep_ld4(const float* base, s
   if constexpr (OB) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off));
   else return *reinterpret_cast<const float4*>(base + off);
 }
+// the same load as raw bits (bf16 storage: 8 bytes in .x / .y) and its conversion: the epilogue requests the raw bits of a
+// whole row tile first and converts at use -- a conversion beside the load, inside the `ok ? load : 0` branch, makes the
+// compiler wait for every load in turn
+template <bool OB> __device__ __forceinline__ float4 ep_ld4_raw(const float* base, size_t off) {
+  if constexpr (OB) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+  } else {
+    return *reinterpret_cast<const float4*>(base + off);
+  }
+}
+template <bool OB> __device__ __forceinline__ float4 ep_cvt4(const float4& r) {
+  if constexpr (OB) return bf16x4_to_f32(make_uint2(__float_as_uint(r.x), __float_as_uint(r.y)));
+  else return r;
+}
 template <bool OB> __device__ __forceinline__ void ep_st4(float* base, size_t off, float a, float b, float c, float d) {
   if constexpr (OB) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = f32x4_to_bf16(a, b, c, d);
   else *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
@@ -297,9 +312,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
         for (int g = 0; g < 4; ++g) {
           const int m = mrow[g] = rowmap(rbase + q + 8 * g);
           const bool ok = nvalid && m >= 0;
-          old4[g] = (a.accumulate && ok) ? ep_ld4<OB>(obase, ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
-          gate4[g] = (a.mask && ok) ? ep_ld4<OB>(a.mask, (size_t)m * a.mask_ld + a.mask_coff + nq)
-                                    : make_float4(1.f, 1.f, 1.f, 1.f);
+          // (raw bits; neutral elements in the raw domain: 0 = +0.0 either way, the gate's 1.0 is 0x3f80 per bf16)
+          old4[g] = (a.accumulate && ok) ? ep_ld4_raw<OB>(obase, ocol + (size_t)m * oldim) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gate4[g] = (a.mask && ok) ? ep_ld4_raw<OB>(a.mask, (size_t)m * a.mask_ld + a.mask_coff + nq)
+                                    : (OB ? make_float4(__uint_as_float(0x3f803f80u), __uint_as_float(0x3f803f80u), 0.f, 0.f)
+                                          : make_float4(1.f, 1.f, 1.f, 1.f));
           // (the raw gate byte; its nibble is taken after all loads of the row tile are out: a value consumed inside
           // its bounds branch is waited for at once)
           unsigned gb = 0xffu;
@@ -336,8 +353,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             }
           }
           if (!nvalid || m < 0) continue;
-          const float o4[4] = {old4[g].x, old4[g].y, old4[g].z, old4[g].w};
-          const float g4[4] = {gate4[g].x, gate4[g].y, gate4[g].z, gate4[g].w};
+          const float4 oc = ep_cvt4<OB>(old4[g]), gc = ep_cvt4<OB>(gate4[g]);
+          const float o4[4] = {oc.x, oc.y, oc.z, oc.w};
+          const float g4[4] = {gc.x, gc.y, gc.z, gc.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             float t = v[k] + o4[k];
