@@ -95,20 +95,24 @@ __global__ __launch_bounds__(256) void freeze_bwd_kernel(
     int px = i % HW;
     int c = i / HW;
     const float* xp = x + ((size_t)(b * C + c) * T) * HW + px;
-    float xv[TT], pv[TT];
+    float xv[TT], pv[TT], gq[TT];
+    // every frame of the pixel (and of its gradient) is requested before the scans start: a load consumed inside
+    // the `u < T` branch is waited for at once, T serial round trips per thread
 #pragma unroll
-    for (int u = 0; u < TT; ++u) {
-      if (u < T) {
-        xv[u] = xp[(size_t)u * HW];
-        pv[u] = u ? (1.f - mp[u]) * xv[u] + mp[u] * pv[u - 1] : xv[u];
-      }
-    }
+    for (int u = 0; u < TT; ++u)
+      if (u < T) xv[u] = xp[(size_t)u * HW];
+#pragma unroll
+    for (int u = 0; u < TT; ++u)
+      if (u < T)
+        gq[u] = g_cpad ? g[((size_t)(b * T + u) * HW + px) * g_cpad + c] : g[((size_t)(b * C + c) * T + u) * HW + px];
+#pragma unroll
+    for (int u = 0; u < TT; ++u)
+      if (u < T) pv[u] = u ? (1.f - mp[u]) * xv[u] + mp[u] * pv[u - 1] : xv[u];
     float G = 0.f;
 #pragma unroll
     for (int u = TT - 1; u >= 0; --u) {
       if (u < T) {
-        float gv = g_cpad ? g[((size_t)(b * T + u) * HW + px) * g_cpad + c]
-                          : g[((size_t)(b * C + c) * T + u) * HW + px];
+        float gv = gq[u];
         float mnext = (u + 1 < T) ? mp[u + 1] : 0.f;
         G = gv + mnext * G;
         if (u > 0) acc[u] += (pv[u - 1] - xv[u]) * G;
@@ -154,13 +158,13 @@ __global__ __launch_bounds__(256) void freeze_bwd_cl4_kernel(
     for (int c = 0; c < C; ++c) {
       const float* xp = x + ((size_t)(b * C + c) * T) * HW + px;
       float xv[TT], pv[TT];
+      // (all frames of the pixel requested before the scan: see freeze_bwd_kernel)
 #pragma unroll
-      for (int u = 0; u < TT; ++u) {
-        if (u < T) {
-          xv[u] = xp[(size_t)u * HW];
-          pv[u] = u ? (1.f - mp[u]) * xv[u] + mp[u] * pv[u - 1] : xv[u];
-        }
-      }
+      for (int u = 0; u < TT; ++u)
+        if (u < T) xv[u] = xp[(size_t)u * HW];
+#pragma unroll
+      for (int u = 0; u < TT; ++u)
+        if (u < T) pv[u] = u ? (1.f - mp[u]) * xv[u] + mp[u] * pv[u - 1] : xv[u];
       float G = 0.f;
 #pragma unroll
       for (int u = TT - 1; u >= 0; --u) {
