@@ -71,6 +71,30 @@ def test_freeze_per_clip_masks_match_oracle():
     assert torch.equal(dm, dm_b)
 
 
+@pytest.mark.parametrize("T", [9, 24, 40])
+def test_freeze_ragged_lengths_match_oracle(T):
+    """Clip lengths that are not a kernel template size (16 / 32 / 64 frames): the guarded frames of the backward's
+    up-front loads stay out of the scans, in both gradient layouts."""
+    import ivf_recipe as R
+    from oracle import mask_ref
+    x = torch.from_numpy(R.uniform(f't/freeze/rag/x{T}', (2, 3, T, 6, 10), 0, 255))
+    m = torch.from_numpy(R.uniform(f't/freeze/rag/m{T}', (2, T), 0, 1))
+    gy = torch.from_numpy(R.uniform(f't/freeze/rag/g{T}', (2, 3, T, 6, 10), -1, 1))
+    mr = m.clone().requires_grad_()
+    xr = x.clone().requires_grad_()
+    pr = mask_ref.freeze(xr, mr)
+    (pr * gy).sum().backward()
+    p = _freeze(x.cuda(), m.cuda(), per_clip=True)
+    dm, dx = _freeze_bwd(x.cuda(), m.cuda(), gy.cuda(), per_clip=True)
+    assert rel_err(p.cpu().numpy(), pr.detach().numpy()) < 1e-6
+    assert rel_err(dm.cpu().numpy(), mr.grad.numpy()) < 1e-5
+    assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < 1e-6
+    gcl = torch.zeros(2, T, 6, 10, 4, device='cuda')
+    gcl[..., :3] = gy.cuda().permute(0, 2, 3, 4, 1)
+    dm2, _ = _freeze_bwd(x.cuda(), m.cuda(), gcl.contiguous(), per_clip=True, cpad=4, want_dx=False)
+    assert rel_err(dm2.cpu().numpy(), mr.grad.numpy()) < 1e-5
+
+
 def test_freeze_edge_masks():
     """all-zero mask = identity, all-one mask = every frame equals frame 0"""
     import ivf_recipe as R
