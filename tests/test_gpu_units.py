@@ -535,7 +535,11 @@ def _pool_desc(L, B, thw, C, k, s, bf16):
 
 
 @pytest.mark.parametrize("k,st,thw,C", [((1, 3, 3), (1, 2, 2), (3, 17, 20), 24), ((3, 3, 3), (2, 2, 2), (5, 15, 14), 40),
-                                        ((2, 2, 2), (2, 2, 2), (4, 8, 10), 16), ((3, 3, 3), (1, 1, 1), (4, 9, 8), 48)])
+                                        ((2, 2, 2), (2, 2, 2), (4, 8, 10), 16), ((3, 3, 3), (1, 1, 1), (4, 9, 8), 48),
+                                        # channel counts that are not a multiple of 8: the 4-channel fallbacks of the
+                                        # 16-byte-per-lane bf16 kernels (no lane pairs, generic forward, 4-channel backward)
+                                        ((3, 3, 3), (1, 1, 1), (4, 9, 8), 12), ((1, 3, 3), (1, 2, 2), (3, 17, 20), 20),
+                                        ((3, 3, 3), (2, 2, 2), (5, 15, 14), 28)])
 def test_maxpool_bf16_storage_equals_fp32_path(k, st, thw, C):
     """Every pool kernel family with bf16 storage (ivf_pool3d_desc.act_bf16) against the fp32 path on the same
     bf16-representable tensors: the forward selects (identical values and arg-max, ties included), the backward sums in
