@@ -241,7 +241,10 @@ def test_maxpool_gate_nonpos_equals_relu_mask(k, st, thw):
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("k,cin,cout,thw", [(3, 32, 40, (5, 15, 30)), (3, 16, 200, (3, 9, 15)), (4, 8, 32, (4, 9, 10)),
-                                            (1, 24, 72, (2, 5, 7))])
+                                            (1, 24, 72, (2, 5, 7)),
+                                            # channel counts that neither divide nor are divided by the 32-deep chunk of the
+                                            # implicit GEMM: its running (tap, channel) state carries across chunks
+                                            (3, 24, 40, (3, 7, 9)), (3, 12, 16, (2, 6, 7)), (2, 40, 24, (3, 6, 5))])
 def test_every_conv_variant_matches_torch(k, cin, cout, thw, math):
     """Every kernel variant the tuner may pick (ivf_conv3d_variants: implicit GEMM tiles, all
     LDS-halo boxes) computes the same convolution: compared with torch's fp64 conv3d on
